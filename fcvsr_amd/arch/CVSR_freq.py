@@ -1,0 +1,209 @@
+"""Drop-in boundary: ``from fcvsr_amd.arch.CVSR_freq import GShiftNet, GShiftNet_S``.
+
+Mirrors the constructor signature, ``forward`` signature and ``state_dict`` schema (303 tensors for S, 678 for the
+full model, including the aliased ``...body.3.*`` / ``...RCB.*`` duplicates and the never-used ``DivEnh.Conv``) of the
+reference classes (reference: CVSR_train/arch/CVSR_freq.py:2577-2646 ``GShiftNet_S``, :2653-2756 ``GShiftNet``), so that
+``model.load_state_dict(torch.load(ckpt))``, ``model.to(device)``, ``model.parameters()`` and ``model(lrs)`` in the
+reference's train/test scripts (test_LD_freqCVSR_S_22.py:51-79) work unchanged.
+
+The modules below are *parameter containers only* (same names, shapes, default initialisation and construction order
+as the reference, so a seeded from-scratch init consumes the RNG identically).  No arithmetic happens in them:
+``forward`` hands raw device pointers to the hand-written HIP kernels in libfcvsr_hip.so via ``fcvsr_amd.engine``.
+There is no CPU / eager fallback - a CPU tensor or a missing library raises.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.init as init
+
+
+class _Holder(nn.Module):
+    """Base for parameter containers: calling one directly is a bug (the engine owns the arithmetic)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError(f"{type(self).__name__} is a parameter container; run the top-level model instead")
+
+
+def _kaiming_scaled(mods, scale):
+    """reference initialize_weights (CVSR_freq.py:635-652): Kaiming-normal(fan_in) * scale, zero bias."""
+    for net in mods:
+        for m in net.modules():
+            if isinstance(m, nn.Conv2d):
+                init.kaiming_normal_(m.weight, a=0, mode="fan_in")
+                m.weight.data *= scale
+                if m.bias is not None:
+                    m.bias.data.zero_()
+
+
+class CALayer(_Holder):  # :1812-1828
+    def __init__(self, channel, reduction=16, bias=False):
+        super().__init__()
+        self.conv_du = nn.Sequential(
+            nn.Conv2d(channel, channel // reduction, 1, padding=0, bias=bias), nn.ReLU(inplace=True),
+            nn.Conv2d(channel // reduction, channel, 1, padding=0, bias=bias), nn.Sigmoid())
+
+
+class ConvBlk(_Holder):  # :344-357
+    def __init__(self, dim=64, index=1):
+        super().__init__()
+        self.k_size = 2 * index + 1
+        self.conv1 = nn.Conv2d(dim, dim, self.k_size, stride=1, padding=self.k_size // 2, bias=False)
+        self.conv2 = nn.Conv2d(dim, dim, self.k_size, stride=1, padding=self.k_size // 2, bias=False)
+        self.relu = nn.PReLU()
+        self.CA = CALayer(dim, 1, bias=False)
+
+
+class MGAAbk(_Holder):  # :1365-1430
+    def __init__(self, dim, wiF=1.5, AC_Ks=3, ACNum=6, bias=False):
+        super().__init__()
+        self.dim, self.wiF, self.AC_Ks, self.ACNum = dim, wiF, AC_Ks, ACNum
+        self.convfuse = nn.Sequential(
+            nn.Conv2d(4 * dim, 2 * dim, 1, bias=bias), nn.ReLU(inplace=True),
+            nn.Conv2d(2 * dim, 2 * dim, 1, bias=bias), nn.ReLU(inplace=True),
+            nn.Conv2d(2 * dim, 2 * dim, 1, bias=bias))
+        self.convcorr = nn.Sequential(
+            nn.Conv2d(2 * dim + 83, dim, 1, bias=bias), nn.ReLU(inplace=True),
+            nn.Conv2d(dim, dim, 1, bias=bias), nn.ReLU(inplace=True),
+            nn.Conv2d(dim, 4, 1, bias=bias))
+        self.MConvB = nn.ModuleList([ConvBlk(dim=4, index=i) for i in range(ACNum)])
+        self.convcrt = nn.Sequential(
+            nn.Conv2d(2 * dim, dim, 1, bias=bias), nn.ReLU(inplace=True), nn.Conv2d(dim, 4, 1, bias=bias))
+        self.conv_KP = nn.Conv2d(dim, dim, 3, padding=1)
+        self.kernel_dim = ACNum * (dim * AC_Ks * 2)
+        self.F = nn.Sequential(nn.Conv2d(dim, dim, 3, padding=1), nn.Conv2d(dim, self.kernel_dim, 1, padding=0))
+        self.conv3 = nn.Conv2d(2 * dim, dim, 3, padding=1, bias=bias)
+
+
+class ContextBlock(_Holder):  # :657-701
+    def __init__(self, n_feat, bias=False):
+        super().__init__()
+        self.conv_mask = nn.Conv2d(n_feat, 1, 1, bias=bias)
+        self.channel_add_conv = nn.Sequential(
+            nn.Conv2d(n_feat, n_feat, 1, bias=bias), nn.LeakyReLU(0.2), nn.Conv2d(n_feat, n_feat, 1, bias=bias))
+
+
+class RCB(_Holder):  # :705-725
+    def __init__(self, n_feat, bias=False):
+        super().__init__()
+        act = nn.LeakyReLU(0.2)
+        self.body = nn.Sequential(nn.Conv2d(n_feat, n_feat, 3, 1, 1, bias=bias), act,
+                                  nn.Conv2d(n_feat, n_feat, 3, 1, 1, bias=bias))
+        self.act = act
+        self.gcnet = ContextBlock(n_feat, bias=bias)
+
+
+class _Interp(nn.Module):  # placeholder keeping Sequential indices of the reference's Interpolate (:623-632)
+    def __init__(self, scale_factor):
+        super().__init__()
+        self.scale_factor = scale_factor
+
+
+class BlockRCB(_Holder):  # :729-777
+    def __init__(self, nf, kernel_size=3, width_multiplier=1):
+        super().__init__()
+        self.RCB = RCB(nf)
+        body = [nn.Conv2d(nf, int(nf * width_multiplier), kernel_size, padding=kernel_size // 2),
+                nn.LeakyReLU(negative_slope=0.1, inplace=True),
+                nn.Conv2d(int(nf * width_multiplier), nf, kernel_size, padding=kernel_size // 2),
+                self.RCB]                      # same module registered twice -> aliased state_dict keys (:736,751)
+        _kaiming_scaled(body, 0.1)
+        self.body = nn.Sequential(*body)
+        self.down = nn.Sequential(nn.Conv2d(nf, nf, 1), _Interp(0.5))
+        self.up = nn.Sequential(nn.Conv2d(nf, nf, 1), _Interp(2.0))
+        _kaiming_scaled([self.up, self.down], 0.1)
+
+
+class SCGroupbk(_Holder):  # :781-803
+    def __init__(self, nf=64, back_RBs=3):
+        super().__init__()
+        self.conv = nn.Conv2d(nf, nf, 3, padding=1)
+        self.body = nn.Sequential(*[BlockRCB(nf, kernel_size=3, width_multiplier=2) for _ in range(back_RBs)])
+
+
+class SCNetbk(_Holder):  # :807-822
+    def __init__(self, nf=64, SCGroupN=4):
+        super().__init__()
+        self.body = nn.Sequential(*[SCGroupbk(nf=nf) for _ in range(SCGroupN)])
+
+
+class DivEnh(_Holder):  # :2104-2133
+    def __init__(self, channel):
+        super().__init__()
+        self.Conv = nn.Conv2d(channel, channel, 3, stride=1, padding=1)   # never used by forward
+        self.a = nn.Parameter(torch.zeros(channel, 1, 1))
+        self.b = nn.Parameter(torch.ones(channel, 1, 1))
+        self.ca = CALayer(channel)
+
+
+class _Split(nn.Module):  # Split_freq has no parameters or buffers (mask is a plain attribute, :2014)
+    pass
+
+
+class MultiFreq_Refinment(_Holder):  # :2183-2199
+    def __init__(self, dim, Freq_Inv=8, mode="gaussian", freq_order="l2h"):
+        super().__init__()
+        if mode != "gaussian" or freq_order != "l2h":
+            raise ValueError("only the configuration used by GShiftNet(_S) is built: gaussian masks, 'l2h' order")
+        self.split = _Split()
+        self.Freq_Inv = Freq_Inv
+        self.DivEnh_block = nn.ModuleList([DivEnh(channel=dim) for _ in range(Freq_Inv)])
+        self.ca = CALayer(dim)
+
+
+class _GShiftBase(nn.Module):
+    _up_k = 1
+    _in_frames = 7
+    _img_ch = 1
+
+    def __init__(self, n_features, wiF, AC_Ks, ACNum, Freq_Inv, SCGroupN):
+        super().__init__()
+        if n_features % 16:
+            raise ValueError("n_features must be a multiple of 16 (CALayer r=16, PixelShuffle splits)")
+        if AC_Ks != 3:
+            raise ValueError("AC_Ks must be 3 (the separable adaptive kernels are 3-tap, CVSR_freq.py:1253)")
+        n, k = n_features, self._up_k
+        self.n_feats = n
+        self.device = torch.device("cuda")
+        self.wiF, self.AC_Ks, self.ACNum, self.Freq_Inv, self.SCGroupN = wiF, AC_Ks, ACNum, Freq_Inv, SCGroupN
+        cin = self._in_frames * self._img_ch
+        self.feat_extract = nn.Sequential(nn.Conv2d(cin, 7 * n, 3, 1, 1))
+        self.lrelu = nn.PReLU()
+        self.MGAA = MGAAbk(dim=n, wiF=wiF, AC_Ks=AC_Ks, ACNum=ACNum)
+        self.rconcat1 = nn.Conv2d(n, n, 3, stride=2, padding=1, bias=True)
+        self.rconcat2 = nn.Conv2d(n, n, 3, stride=2, padding=1, bias=True)
+        self.recorb1 = SCNetbk(nf=n, SCGroupN=SCGroupN)
+        self.recorb0 = nn.Conv2d(n, n, 3, 1, 1, bias=True)
+        self.upconv1_L2 = nn.Conv2d(n, n, k, 1, k // 2, bias=True)
+        self.upconv1_L2_2 = nn.Conv2d(n + n // 4, n, k, 1, k // 2, bias=True)
+        self.upconv1_L3 = nn.Conv2d(n, n, k, 1, k // 2, bias=True)
+        self.upconv1 = nn.Conv2d(n, n * 4, k, 1, k // 2, bias=True)
+        self.upconv2 = nn.Conv2d(n, n * 4, k, 1, k // 2, bias=True)
+        self.pixel_shuffle = nn.PixelShuffle(2)
+        self.conv_last0 = nn.Conv2d(n, self._img_ch, 3, 1, 1, bias=True)
+        self.MFFRblock = MultiFreq_Refinment(dim=n, Freq_Inv=Freq_Inv, mode="gaussian")
+        self.upconv_fuse = nn.Conv2d(n + n // 4 + n // 16, n, 3, 1, 1, bias=True)
+        self._engine = None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x: float (B, 7, C, H, W) in [0,1] on a HIP device -> (B, C, 4H, 4W)."""
+        from ..engine import Engine
+        if self._engine is None:
+            object.__setattr__(self, "_engine", Engine(self))
+        return self._engine.forward(x)
+
+
+class GShiftNet_S(_GShiftBase):
+    """FCVSR-S, Y channel (reference CVSR_freq.py:2577-2646): 1x1 up-convs."""
+    _up_k = 1
+
+    def __init__(self, n_features=64, wiF=1.5, AC_Ks=3, ACNum=3, Freq_Inv=4, SCGroupN=4):
+        super().__init__(n_features, wiF, AC_Ks, ACNum, Freq_Inv, SCGroupN)
+
+
+class GShiftNet(_GShiftBase):
+    """FCVSR, Y channel (reference CVSR_freq.py:2653-2756): 3x3 up-convs."""
+    _up_k = 3
+
+    def __init__(self, n_features=64, wiF=1.5, AC_Ks=3, ACNum=6, Freq_Inv=8, SCGroupN=10):
+        super().__init__(n_features, wiF, AC_Ks, ACNum, Freq_Inv, SCGroupN)

@@ -1,0 +1,282 @@
+// Batched 2-D real FFT / inverse for NHWC channel groups on gfx950, any length (mixed radix, any prime factor).
+//
+// Design (MI355X-first): with channels innermost, BOTH passes of the 2-D transform vectorise over channels:
+//   * a lane owns one (element, channel) pair; L consecutive lanes are L consecutive channels of the same pixel, so every
+//     HBM access of either pass is an L*4-byte contiguous segment and every LDS access is conflict-free along channels;
+//   * the whole 1-D transform of L channels lives in LDS (two ping-pong complex buffers, Stockham autosort), one
+//     workgroup per (image row | spectrum column, channel chunk); no transposes through HBM;
+//   * real rows use the two-for-one trick: channels c and c+L ride as the real and imaginary part of one complex FFT.
+// A Stockham stage of radix r computes y[o] = sum_q x[j+q*N/r] * W_N^(q*(k+p*Ns)*N/(Ns*r)) directly (r MACs per output),
+// which supports any radix without register arrays; total cost N*sum(r_i) complex MACs per transform.
+// Twiddles are generated per workgroup in f64 (sincospi) and rounded once to f32, like pocketfft's table.
+//
+// Replaces torch.fft.rfft2 / irfft2 (CVSR_freq.py:1452-1454, :1499, :1504) and the per-channel
+// fftn/fftshift/mask/ifftshift/ifftn(.real) loop of Split_freq (:2082-2090, via the symmetrised half-spectrum mask).
+#include "common.h"
+
+namespace fcvsr {
+
+struct FftPlan {
+  int N;
+  int nfac;
+  int fac[20];
+};
+
+static bool make_plan(int N, FftPlan* p) {
+  p->N = N;
+  p->nfac = 0;
+  int n = N;
+  while (n % 4 == 0) { p->fac[p->nfac++] = 4; n /= 4; }
+  while (n % 2 == 0) { p->fac[p->nfac++] = 2; n /= 2; }
+  for (int f = 3; f <= n; f += 2) {
+    while (n % f == 0) {
+      if (p->nfac >= 20) return false;
+      p->fac[p->nfac++] = f;
+      n /= f;
+    }
+  }
+  if (N == 1) { p->fac[0] = 1; p->nfac = 1; }
+  return n == 1;
+}
+
+// LDS layout (floats): re0[N*L] im0[N*L] re1[N*L] im1[N*L] tw[2*N]
+__device__ __forceinline__ void make_twiddles(float* tw, int N, bool inverse) {
+  for (int m = threadIdx.x; m < N; m += blockDim.x) {
+    double s, c;
+    sincospi(2.0 * (double)m / (double)N, &s, &c);
+    tw[2 * m] = (float)c;
+    tw[2 * m + 1] = inverse ? (float)s : (float)(-s);
+  }
+}
+
+// runs all stages; returns 0 if the result is in buffer 0, 1 if in buffer 1
+__device__ __forceinline__ int run_stages(float* lds, const FftPlan& plan, int L) {
+  const int N = plan.N;
+  const int NL = N * L;
+  const float* tw = lds + 4 * NL;
+  int cur = 0;
+  int Ns = 1;
+  for (int s = 0; s < plan.nfac; ++s) {
+    const int r = plan.fac[s];
+    const int M = N / r;
+    const int span = Ns * r;
+    const int mult = N / span;
+    const float* xr = lds + cur * 2 * NL;
+    const float* xi = xr + NL;
+    float* yr = lds + (cur ^ 1) * 2 * NL;
+    float* yi = yr + NL;
+    for (int t = threadIdx.x; t < NL; t += blockDim.x) {
+      const int l = t % L;
+      const int o = t / L;
+      const int k = o % Ns;
+      const int p = (o / Ns) % r;
+      const int jhi = o / span;
+      const int j = jhi * Ns + k;
+      const int step = k + p * Ns;
+      int e = 0;
+      float ar = 0.f, ai = 0.f;
+      for (int q = 0; q < r; ++q) {
+        const int idx = (j + q * M) * L + l;
+        const float vr = xr[idx], vi = xi[idx];
+        const float wr = tw[2 * e * mult], wi = tw[2 * e * mult + 1];
+        ar = fmaf(vr, wr, ar); ar = fmaf(-vi, wi, ar);
+        ai = fmaf(vr, wi, ai); ai = fmaf(vi, wr, ai);
+        e += step;
+        if (e >= span) e -= span;
+      }
+      yr[o * L + l] = ar;
+      yi[o * L + l] = ai;
+    }
+    __syncthreads();
+    cur ^= 1;
+    Ns = span;
+  }
+  return cur;
+}
+
+// ---- forward rows: real (B,H,W,n) -> half spectrum, two channels per complex lane -------------------------------
+__global__ __launch_bounds__(512) void rfft_rows_kernel(View src, int n, int H, int W, int L, float* spec,
+                                                        long long ps, int im_off, int re_off, FftPlan plan) {
+  extern __shared__ __align__(16) float lds[];
+  const int NL = W * L;
+  const int b = blockIdx.x / H, y = blockIdx.x % H;
+  const int c0 = blockIdx.y * 2 * L;
+  const int Wf = W / 2 + 1;
+  make_twiddles(lds + 4 * NL, W, false);
+  const float* sp = src.p + (long long)b * src.sb + (long long)y * src.sy;
+  for (int t = threadIdx.x; t < NL; t += blockDim.x) {
+    const int l = t % L, x = t / L;
+    const int ca = c0 + l, cb = c0 + L + l;
+    const float* px = sp + (long long)x * src.sx;
+    lds[t] = ca < n ? px[(long long)ca * src.sc] : 0.f;
+    lds[NL + t] = cb < n ? px[(long long)cb * src.sc] : 0.f;
+  }
+  __syncthreads();
+  const int cur = run_stages(lds, plan, L);
+  const float* zr = lds + (cur ? 2 * NL : 0);
+  const float* zi = zr + NL;
+  float* op = spec + ((long long)(b * H + y) * Wf) * ps;
+  for (int t = threadIdx.x; t < Wf * L; t += blockDim.x) {
+    const int l = t % L, k = t / L;
+    const int kn = (W - k) % W;
+    const float kr = zr[k * L + l], ki = zi[k * L + l];
+    const float nr = zr[kn * L + l], ni = zi[kn * L + l];
+    const int ca = c0 + l, cb = c0 + L + l;
+    float* o = op + (long long)k * ps;
+    if (ca < n) { o[re_off + ca] = 0.5f * (kr + nr); o[im_off + ca] = 0.5f * (ki - ni); }
+    if (cb < n) { o[re_off + cb] = 0.5f * (ki + ni); o[im_off + cb] = 0.5f * (nr - kr); }
+  }
+}
+
+// ---- columns: complex length-H transform of spectrum columns, forward or inverse, optional real mask -----------
+__global__ __launch_bounds__(512) void fft_cols_kernel(const float* in, float* out, long long ps, int im_off, int re_off,
+                                                       int n, int H, int Wf, int L, int inverse, const float* mask,
+                                                       FftPlan plan) {
+  extern __shared__ __align__(16) float lds[];
+  const int NL = H * L;
+  const int b = blockIdx.x / Wf, kx = blockIdx.x % Wf;
+  const int c0 = blockIdx.y * L;
+  make_twiddles(lds + 4 * NL, H, inverse != 0);
+  for (int t = threadIdx.x; t < NL; t += blockDim.x) {
+    const int l = t % L, y = t / L;
+    const int c = c0 + l;
+    const float* px = in + ((long long)(b * H + y) * Wf + kx) * ps;
+    const float m = mask ? mask[y * Wf + kx] : 1.f;
+    lds[t] = c < n ? px[re_off + c] * m : 0.f;
+    lds[NL + t] = c < n ? px[im_off + c] * m : 0.f;
+  }
+  __syncthreads();
+  const int cur = run_stages(lds, plan, L);
+  const float* zr = lds + (cur ? 2 * NL : 0);
+  const float* zi = zr + NL;
+  for (int t = threadIdx.x; t < NL; t += blockDim.x) {
+    const int l = t % L, y = t / L;
+    const int c = c0 + l;
+    if (c < n) {
+      float* px = out + ((long long)(b * H + y) * Wf + kx) * ps;
+      px[re_off + c] = zr[t];
+      px[im_off + c] = zi[t];
+    }
+  }
+}
+
+// ---- inverse rows: half spectrum -> real (c2r semantics: imag of DC / Nyquist ignored), two channels per lane ----
+__global__ __launch_bounds__(512) void irfft_rows_kernel(const float* spec, long long ps, int im_off, int re_off, int n,
+                                                         int H, int W, int L, View dst, float scale, FftPlan plan) {
+  extern __shared__ __align__(16) float lds[];
+  const int NL = W * L;
+  const int b = blockIdx.x / H, y = blockIdx.x % H;
+  const int c0 = blockIdx.y * 2 * L;
+  const int Wf = W / 2 + 1;
+  make_twiddles(lds + 4 * NL, W, true);
+  const float* ip = spec + ((long long)(b * H + y) * Wf) * ps;
+  for (int t = threadIdx.x; t < NL; t += blockDim.x) {
+    const int l = t % L, k = t / L;
+    const int kk = (k <= W / 2) ? k : W - k;
+    const bool cj = k > W / 2;
+    const bool real_only = (kk == 0) || ((W % 2 == 0) && kk == W / 2);
+    const int ca = c0 + l, cb = c0 + L + l;
+    const float* px = ip + (long long)kk * ps;
+    float ar = 0.f, ai = 0.f, br = 0.f, bi = 0.f;
+    if (ca < n) { ar = px[re_off + ca]; ai = px[im_off + ca]; }
+    if (cb < n) { br = px[re_off + cb]; bi = px[im_off + cb]; }
+    if (real_only) { ai = 0.f; bi = 0.f; }
+    if (cj) { ai = -ai; bi = -bi; }
+    lds[t] = ar - bi;        // Z = Xa + i*Xb
+    lds[NL + t] = ai + br;
+  }
+  __syncthreads();
+  const int cur = run_stages(lds, plan, L);
+  const float* zr = lds + (cur ? 2 * NL : 0);
+  const float* zi = zr + NL;
+  float* op = dst.p + (long long)b * dst.sb + (long long)y * dst.sy;
+  for (int t = threadIdx.x; t < NL; t += blockDim.x) {
+    const int l = t % L, x = t / L;
+    const int ca = c0 + l, cb = c0 + L + l;
+    float* px = op + (long long)x * dst.sx;
+    if (ca < n) px[(long long)ca * dst.sc] = zr[t] * scale;
+    if (cb < n) px[(long long)cb * dst.sc] = zi[t] * scale;
+  }
+}
+
+static int pick_lanes(int N, int n_lanes_needed) {
+  // LDS bytes = 16*N*L + 8*N, budget 128 KiB; L power of two in [1,32]
+  int L = 32;
+  while (L > 1 && (16ll * N * L + 8ll * N) > 128 * 1024) L >>= 1;
+  while (L > 1 && L / 2 >= n_lanes_needed) L >>= 1;
+  return L;
+}
+
+template <class K>
+static hipError_t allow_lds(K kernel, size_t bytes) {
+  return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace fcvsr
+
+using namespace fcvsr;
+
+extern "C" int fcvsr_rfft2(const fcvsr_view* src, int B, int H, int W, int n, float* spec, int64_t pix_stride,
+                           int im_off, int re_off, void* stream) {
+  FCVSR_CHECK_ARG(src && src->ptr && spec, "null pointer");
+  FCVSR_CHECK_ARG(src->dtype == FCVSR_F32, "f32 only");
+  FCVSR_CHECK_ARG(B > 0 && H > 0 && W > 1 && n > 0 && n <= src->c, "bad sizes");
+  FftPlan pw, ph;
+  FCVSR_CHECK_ARG(make_plan(W, &pw) && make_plan(H, &ph), "length has too many factors");
+  const int Wf = W / 2 + 1;
+  hipStream_t st = (hipStream_t)stream;
+  {
+    const int L = pick_lanes(W, (n + 1) / 2);
+    FCVSR_CHECK_ARG(16ll * W * L + 8ll * W <= 160 * 1024, "row too long for LDS");
+    const size_t lds = 16ull * W * L + 8ull * W;
+    (void)allow_lds(rfft_rows_kernel, lds);
+    dim3 grid(B * H, cdiv(n, 2 * L));
+    hipLaunchKernelGGL(rfft_rows_kernel, grid, dim3(512), lds, st, to_view(*src), n, H, W, L, spec,
+                       (long long)pix_stride, im_off, re_off, pw);
+    FCVSR_LAUNCH_CHECK();
+  }
+  {
+    const int L = pick_lanes(H, n);
+    FCVSR_CHECK_ARG(16ll * H * L + 8ll * H <= 160 * 1024, "column too long for LDS");
+    const size_t lds = 16ull * H * L + 8ull * H;
+    (void)allow_lds(fft_cols_kernel, lds);
+    dim3 grid(B * Wf, cdiv(n, L));
+    hipLaunchKernelGGL(fft_cols_kernel, grid, dim3(512), lds, st, (const float*)spec, spec, (long long)pix_stride, im_off,
+                       re_off, n, H, Wf, L, 0, (const float*)nullptr, ph);
+    FCVSR_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int fcvsr_irfft2(const float* spec, int64_t pix_stride, int im_off, int re_off, int B, int H, int W, int n,
+                            const float* mask, float* work, const fcvsr_view* dst, void* stream) {
+  FCVSR_CHECK_ARG(spec && dst && dst->ptr, "null pointer");
+  FCVSR_CHECK_ARG(dst->dtype == FCVSR_F32, "f32 only");
+  FCVSR_CHECK_ARG(B > 0 && H > 0 && W > 1 && n > 0 && n <= dst->c, "bad sizes");
+  FftPlan pw, ph;
+  FCVSR_CHECK_ARG(make_plan(W, &pw) && make_plan(H, &ph), "length has too many factors");
+  const int Wf = W / 2 + 1;
+  hipStream_t st = (hipStream_t)stream;
+  float* mid = work ? work : const_cast<float*>(spec);
+  {
+    const int L = pick_lanes(H, n);
+    FCVSR_CHECK_ARG(16ll * H * L + 8ll * H <= 160 * 1024, "column too long for LDS");
+    const size_t lds = 16ull * H * L + 8ull * H;
+    (void)allow_lds(fft_cols_kernel, lds);
+    dim3 grid(B * Wf, cdiv(n, L));
+    hipLaunchKernelGGL(fft_cols_kernel, grid, dim3(512), lds, st, spec, mid, (long long)pix_stride, im_off, re_off, n, H,
+                       Wf, L, 1, mask, ph);
+    FCVSR_LAUNCH_CHECK();
+  }
+  {
+    const int L = pick_lanes(W, (n + 1) / 2);
+    FCVSR_CHECK_ARG(16ll * W * L + 8ll * W <= 160 * 1024, "row too long for LDS");
+    const size_t lds = 16ull * W * L + 8ull * W;
+    (void)allow_lds(irfft_rows_kernel, lds);
+    dim3 grid(B * H, cdiv(n, 2 * L));
+    hipLaunchKernelGGL(irfft_rows_kernel, grid, dim3(512), lds, st, (const float*)mid, (long long)pix_stride, im_off,
+                       re_off, n, H, W, L, to_view(*dst), 1.0f / ((float)H * (float)W), pw);
+    FCVSR_LAUNCH_CHECK();
+  }
+  return 0;
+}

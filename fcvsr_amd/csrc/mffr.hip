@@ -1,0 +1,112 @@
+// MultiFreq_Refinment elementwise kernels (reference CVSR_freq.py:2104-2133 DivEnh, :2201-2254).
+// The band split itself is fcvsr_rfft2 + masked fcvsr_irfft2 (fft.hip).  Everything here is HBM-bound streaming over dense
+// NHWC (B,H,W,C) f32 tensors; reductions are deterministic two-stage sums (reduce.h).
+#include "common.h"
+#include "reduce.h"
+
+namespace fcvsr {
+
+struct DivEnhExprF {
+  const float* f;
+  const float* s_f;
+  const float* s_o;
+  const float* a;
+  const float* b;
+  const float* mean_sum;  // [B][C] sums of f (first block only)
+  float inv_hw;
+  long long HW;
+  int C;
+  int first;
+  __device__ void eval(int bi, long long p, int c, float& e1, float& e2, float& fv) const {
+    const long long i = ((long long)bi * HW + p) * C + c;
+    fv = f[i];
+    const float aa = 0.2f * a[c], bb = b[c];
+    if (first) {
+      const float t = fv - mean_sum[bi * C + c] * inv_hw;
+      e1 = aa * t * fv + bb * fv;
+      e2 = 0.f;
+    } else {
+      const float so = s_o[i];
+      const float t = fv - s_f[i] + 0.2f * so;
+      e1 = aa * t * fv + bb * fv;
+      e2 = aa * so * fv + bb * fv;
+    }
+  }
+  __device__ void operator()(int bi, long long p, int c, float* out) const {
+    float e1, e2, fv;
+    eval(bi, p, c, e1, e2, fv);
+    out[0] = e1;
+    out[1] = e2;
+  }
+};
+
+__global__ void divenh_apply_kernel(DivEnhExprF ex, float* s_f, float* s_o, const float* g1, const float* g2, int B) {
+  const long long total = (long long)B * ex.HW * ex.C;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int c = (int)(t % ex.C);
+  const long long pg = t / ex.C;
+  const long long p = pg % ex.HW;
+  const int bi = (int)(pg / ex.HW);
+  float e1, e2, fv;
+  ex.eval(bi, p, c, e1, e2, fv);
+  float o = e1 * g1[bi * ex.C + c];
+  if (!ex.first) o += e2 * g2[bi * ex.C + c];
+  if (ex.first) { s_f[t] = fv; s_o[t] = o; }
+  else { s_f[t] += fv; s_o[t] += o; }
+}
+
+__global__ void scale_add_kernel(const float4* z, const float* gate, const float4* x, float4* out, long long HWCq, int Cq,
+                                 long long total) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int b = (int)(t / HWCq);
+  const int cq = (int)(t % Cq);
+  const float* g = gate + (long long)b * Cq * 4 + cq * 4;
+  const float4 zz = z[t], xx = x[t];
+  out[t] = make_float4(fmaf(zz.x, g[0], xx.x), fmaf(zz.y, g[1], xx.y), fmaf(zz.z, g[2], xx.z), fmaf(zz.w, g[3], xx.w));
+}
+
+}  // namespace fcvsr
+
+using namespace fcvsr;
+
+extern "C" int fcvsr_divenh(int mode, int first, const float* f, float* s_f, float* s_o, const float* a, const float* b,
+                            const float* mean_f_sum, float inv_hw, const float* g1, const float* g2, float* sums,
+                            float* scratch, int64_t scratch_elems, int B, int H, int W, int C, void* stream) {
+  FCVSR_CHECK_ARG(f && s_f && s_o && a && b, "null pointer");
+  FCVSR_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C <= 256, "bad sizes");
+  FCVSR_CHECK_ARG(!first || mean_f_sum, "first block needs the sums of f");
+  DivEnhExprF ex{f, s_f, s_o, a, b, mean_f_sum, inv_hw, (long long)H * W, C, first};
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 0) {
+    FCVSR_CHECK_ARG(sums && scratch, "reduce mode needs sums and scratch");
+    const int nblk = red_blocks(ex.HW);
+    FCVSR_CHECK_ARG(scratch_elems >= 2ll * B * nblk * C, "scratch too small");
+    hipLaunchKernelGGL((reduce_stage1<2, DivEnhExprF>), dim3(nblk, B), dim3(kRedThreads), 0, st, ex, B, ex.HW, C, scratch);
+    FCVSR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_stage2, dim3(cdiv(2ll * B * C, 256)), dim3(256), 0, st, (const float*)scratch, 2 * B, nblk, C,
+                       sums);
+    FCVSR_LAUNCH_CHECK();
+  } else {
+    FCVSR_CHECK_ARG(g1 && (first || g2), "apply mode needs gates");
+    const long long total = (long long)B * H * W * C;
+    hipLaunchKernelGGL(divenh_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, ex, s_f, s_o, g1, g2, B);
+    FCVSR_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int fcvsr_scale_add(const float* z, const float* gate, const float* x, float* out, int B, int H, int W, int C,
+                               void* stream) {
+  FCVSR_CHECK_ARG(z && gate && x && out, "null pointer");
+  FCVSR_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "C%4==0 required");
+  FCVSR_CHECK_ARG(((uintptr_t)z % 16 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0), "16-byte alignment");
+  const int Cq = C / 4;
+  const long long HWCq = (long long)H * W * Cq;
+  const long long total = HWCq * B;
+  hipLaunchKernelGGL(scale_add_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)z, gate,
+                     (const float4*)x, (float4*)out, HWCq, Cq, total);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,56 @@
+// Deterministic two-stage per-(batch, channel) reductions over pixels (no float atomics: fixed summation order).
+#pragma once
+#include "common.h"
+
+namespace fcvsr {
+
+constexpr int kRedThreads = 256;
+constexpr int kRedPix = 1024;  // pixels per stage-1 block
+
+inline int red_blocks(long long npix) { return cdiv(npix, kRedPix); }
+
+// Stage 1: partial[k][b][blk][c] = sum over this block's pixels of f(b, pix, c)[k].
+// Thread (sub, c): sub = tid / C strides over pixels; lanes with consecutive tid read consecutive channels.
+template <int K, class F>
+__global__ __launch_bounds__(kRedThreads) void reduce_stage1(F f, int B, long long npix, int C, float* partial) {
+  __shared__ float sm[K][kRedThreads];
+  const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+  const int R = kRedThreads / C;  // pixel sub-lanes (C <= 256)
+  const int sub = threadIdx.x / C, c = threadIdx.x % C;
+  float acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = 0.f;
+  if (sub < R) {
+    const long long p0 = (long long)blk * kRedPix;
+    const long long p1 = (p0 + kRedPix < npix) ? p0 + kRedPix : npix;
+    for (long long p = p0 + sub; p < p1; p += R) {
+      float v[K];
+      f(b, p, c, v);
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[k] += v[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) sm[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < C) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float s = 0.f;
+      for (int r = 0; r < R; ++r) s += sm[k][r * C + threadIdx.x];
+      partial[(((long long)k * B + b) * nblk + blk) * C + threadIdx.x] = s;
+    }
+  }
+}
+
+// Stage 2: out[kb][c] = sum_blk partial[kb][blk][c]   (kb in [0, K*B))
+static __global__ void reduce_stage2(const float* partial, int KB, int nblk, int C, float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= KB * C) return;
+  const int kb = i / C, c = i % C;
+  float s = 0.f;
+  for (int blk = 0; blk < nblk; ++blk) s += partial[((long long)kb * nblk + blk) * C + c];
+  out[i] = s;
+}
+
+}  // namespace fcvsr

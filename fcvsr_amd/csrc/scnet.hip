@@ -1,0 +1,222 @@
+// SCNetbk non-conv kernels (reference CVSR_freq.py:657-777): ContextBlock global softmax pooling + MLP, RCB tail,
+// BlockRCB cross-scale sum (2x2 mean down, bilinear x2 up).  Dense NHWC (B,H,W,C) f32.
+#include "common.h"
+
+namespace fcvsr {
+
+constexpr int kGcPix = 256;  // pixels per stage-1 block (= threads)
+
+// Stage 1: per block of 256 pixels: logits l_p = r_p . wmask, m = max l, e_p = exp(l_p - m),
+// part[b][blk][0..C) = sum_p e_p r_p[c], part[..][C] = m, part[..][C+1] = sum_p e_p
+__global__ __launch_bounds__(kGcPix) void gc_stage1_kernel(const float* r, const float* wmask, long long HW, int C,
+                                                           float* part) {
+  __shared__ float e_s[kGcPix];
+  __shared__ float red[kGcPix];
+  const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+  const long long p = (long long)blk * kGcPix + threadIdx.x;
+  const bool live = p < HW;
+  float logit = -INFINITY;
+  if (live) {
+    const float4* rp = reinterpret_cast<const float4*>(r + ((long long)b * HW + p) * C);
+    const float4* wp = reinterpret_cast<const float4*>(wmask);
+    float s = 0.f;
+    for (int q = 0; q < C / 4; ++q) {
+      const float4 v = rp[q], w = wp[q];
+      s = fmaf(v.x, w.x, s); s = fmaf(v.y, w.y, s); s = fmaf(v.z, w.z, s); s = fmaf(v.w, w.w, s);
+    }
+    logit = s;
+  }
+  red[threadIdx.x] = logit;
+  __syncthreads();
+  for (int st = kGcPix / 2; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+    __syncthreads();
+  }
+  const float m = red[0];
+  __syncthreads();
+  const float e = live ? expf(logit - m) : 0.f;
+  e_s[threadIdx.x] = e;
+  red[threadIdx.x] = e;
+  __syncthreads();
+  for (int st = kGcPix / 2; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  const float esum = red[0];
+  __syncthreads();
+  // weighted channel sums: thread (sub, c)
+  const int R = kGcPix / C;
+  const int sub = threadIdx.x / C, c = threadIdx.x % C;
+  float acc = 0.f;
+  if (sub < R) {
+    const long long p0 = (long long)blk * kGcPix;
+    const int np = (int)((HW - p0 < kGcPix) ? (HW - p0) : kGcPix);
+    for (int q = sub; q < np; q += R) acc = fmaf(e_s[q], r[((long long)b * HW + p0 + q) * C + c], acc);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  float* out = part + ((long long)b * nblk + blk) * (C + 2);
+  if (threadIdx.x < C) {
+    float s = 0.f;
+    for (int q = 0; q < R; ++q) s += red[q * C + threadIdx.x];
+    out[threadIdx.x] = s;
+  }
+  if (threadIdx.x == 0) { out[C] = m; out[C + 1] = esum; }
+}
+
+// Stage 2 (one block per batch item): combine partials, context -> 1x1 -> LeakyReLU(0.2) -> 1x1
+__global__ void gc_stage2_kernel(const float* part, int nblk, int C, const float* w1, const float* w2, float* add) {
+  extern __shared__ float sm[];  // ctx[C], hid[C], scale[nblk]
+  float* ctx = sm;
+  float* hid = sm + C;
+  float* scale = sm + 2 * C;
+  __shared__ float gmax_s, denom_s;
+  const int b = blockIdx.x;
+  const float* pb = part + (long long)b * nblk * (C + 2);
+  if (threadIdx.x == 0) {
+    float gm = -INFINITY;
+    for (int k = 0; k < nblk; ++k) gm = fmaxf(gm, pb[(long long)k * (C + 2) + C]);
+    float den = 0.f;
+    for (int k = 0; k < nblk; ++k) {
+      const float sc = expf(pb[(long long)k * (C + 2) + C] - gm);
+      den = fmaf(pb[(long long)k * (C + 2) + C + 1], sc, den);
+    }
+    gmax_s = gm;
+    denom_s = den;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < nblk; k += blockDim.x) scale[k] = expf(pb[(long long)k * (C + 2) + C] - gmax_s);
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s = fmaf(pb[(long long)k * (C + 2) + c], scale[k], s);
+    ctx[c] = s / denom_s;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < C; o += blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s = fmaf(w1[o * C + c], ctx[c], s);
+    hid[o] = s >= 0.f ? s : 0.2f * s;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < C; o += blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s = fmaf(w2[o * C + c], hid[c], s);
+    add[(long long)b * C + o] = s;
+  }
+}
+
+__global__ void gc_apply_kernel(const float4* r, const float* add, const float4* z, float4* out, float slope,
+                                long long HWCq, int Cq, long long total) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int b = (int)(t / HWCq);
+  const int cq = (int)(t % Cq);
+  const float* a = add + (long long)b * Cq * 4 + cq * 4;
+  const float4 rr = r[t], zz = z[t];
+  float4 v = make_float4(rr.x + a[0], rr.y + a[1], rr.z + a[2], rr.w + a[3]);
+  v.x = v.x >= 0.f ? v.x : v.x * slope; v.y = v.y >= 0.f ? v.y : v.y * slope;
+  v.z = v.z >= 0.f ? v.z : v.z * slope; v.w = v.w >= 0.f ? v.w : v.w * slope;
+  out[t] = make_float4(v.x + zz.x, v.y + zz.y, v.z + zz.z, v.w + zz.w);
+}
+
+__device__ __forceinline__ float4 f4_axpy(float a, float4 x, float4 y) {
+  return make_float4(fmaf(a, x.x, y.x), fmaf(a, x.y, y.y), fmaf(a, x.z, y.z), fmaf(a, x.w, y.w));
+}
+
+// out = x + rs*r + mean2x2(dn) + bilinear_x2(up)   (F.interpolate align_corners=False semantics)
+__global__ void xscale_kernel(const float4* x, const float4* r, float rs, const float4* dn, const float4* up, float4* out,
+                              int B, int H, int W, int Cq) {
+  const long long total = (long long)B * H * W * Cq;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int cq = (int)(t % Cq);
+  const long long pg = t / Cq;
+  const int xx = (int)(pg % W);
+  const int yy = (int)((pg / W) % H);
+  const int b = (int)(pg / ((long long)W * H));
+  float4 acc = f4_axpy(rs, r[t], x[t]);
+  if (dn) {
+    const int H2 = 2 * H, W2 = 2 * W;
+    const float4* d = dn + ((long long)b * H2 * W2) * Cq + cq;
+    const float4 a00 = d[((long long)(2 * yy) * W2 + 2 * xx) * Cq];
+    const float4 a01 = d[((long long)(2 * yy) * W2 + 2 * xx + 1) * Cq];
+    const float4 a10 = d[((long long)(2 * yy + 1) * W2 + 2 * xx) * Cq];
+    const float4 a11 = d[((long long)(2 * yy + 1) * W2 + 2 * xx + 1) * Cq];
+    // torch upsample_bilinear2d order: lerp along x inside each row, then along y (weights 0.5)
+    const float4 top = make_float4(0.5f * a00.x + 0.5f * a01.x, 0.5f * a00.y + 0.5f * a01.y, 0.5f * a00.z + 0.5f * a01.z,
+                                   0.5f * a00.w + 0.5f * a01.w);
+    const float4 bot = make_float4(0.5f * a10.x + 0.5f * a11.x, 0.5f * a10.y + 0.5f * a11.y, 0.5f * a10.z + 0.5f * a11.z,
+                                   0.5f * a10.w + 0.5f * a11.w);
+    acc = f4_axpy(0.5f, top, acc);
+    acc = f4_axpy(0.5f, bot, acc);
+  }
+  if (up) {
+    const int Hh = H / 2, Wh = W / 2;
+    float sy = 0.5f * ((float)yy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+    float sx = 0.5f * ((float)xx + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < Hh - 1 ? 1 : 0), x1 = x0 + (x0 < Wh - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float4* u = up + ((long long)b * Hh * Wh) * Cq + cq;
+    const float4 u00 = u[((long long)y0 * Wh + x0) * Cq], u01 = u[((long long)y0 * Wh + x1) * Cq];
+    const float4 u10 = u[((long long)y1 * Wh + x0) * Cq], u11 = u[((long long)y1 * Wh + x1) * Cq];
+    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+    acc = f4_axpy(w00, u00, acc);
+    acc = f4_axpy(w01, u01, acc);
+    acc = f4_axpy(w10, u10, acc);
+    acc = f4_axpy(w11, u11, acc);
+  }
+  out[t] = acc;
+}
+
+}  // namespace fcvsr
+
+using namespace fcvsr;
+
+static bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
+
+extern "C" int fcvsr_gc_context(const float* r, const float* wmask, const float* w1, const float* w2, int B, int H, int W,
+                                int C, float* add, float* scratch, int64_t scratch_elems, void* stream) {
+  FCVSR_CHECK_ARG(r && wmask && w1 && w2 && add && scratch, "null pointer");
+  FCVSR_CHECK_ARG(B > 0 && H > 0 && W > 0 && C >= 4 && C <= 256 && C % 4 == 0, "C in 4..256, C%4==0");
+  FCVSR_CHECK_ARG(al16(r) && al16(wmask), "16-byte alignment");
+  const long long HW = (long long)H * W;
+  const int nblk = cdiv(HW, kGcPix);
+  FCVSR_CHECK_ARG(scratch_elems >= (long long)B * nblk * (C + 2), "scratch too small");
+  FCVSR_CHECK_ARG((2ll * C + nblk) * 4 <= 60 * 1024, "image too large for stage-2 LDS");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gc_stage1_kernel, dim3(nblk, B), dim3(kGcPix), 0, st, r, wmask, HW, C, scratch);
+  FCVSR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gc_stage2_kernel, dim3(B), dim3(256), (2 * C + nblk) * sizeof(float), st, (const float*)scratch, nblk,
+                     C, w1, w2, add);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fcvsr_gc_apply(const float* r, const float* add, const float* z, float* out, float slope, int B, int H,
+                              int W, int C, void* stream) {
+  FCVSR_CHECK_ARG(r && add && z && out, "null pointer");
+  FCVSR_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "C%4==0 required");
+  FCVSR_CHECK_ARG(al16(r) && al16(z) && al16(out), "16-byte alignment");
+  const int Cq = C / 4;
+  const long long HWCq = (long long)H * W * Cq;
+  const long long total = HWCq * B;
+  hipLaunchKernelGGL(gc_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)r, add,
+                     (const float4*)z, (float4*)out, slope, HWCq, Cq, total);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fcvsr_xscale(const float* x, const float* r, float r_scale, const float* dn, const float* up, float* out,
+                            int B, int H, int W, int C, void* stream) {
+  FCVSR_CHECK_ARG(x && r && out, "null pointer");
+  FCVSR_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "C%4==0 required");
+  FCVSR_CHECK_ARG(!up || (H % 2 == 0 && W % 2 == 0), "up source needs even H,W");
+  FCVSR_CHECK_ARG(al16(x) && al16(r) && al16(out) && al16(dn) && al16(up), "16-byte alignment");
+  const long long total = (long long)B * H * W * (C / 4);
+  hipLaunchKernelGGL(xscale_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                     (const float4*)r, r_scale, (const float4*)dn, (const float4*)up, (float4*)out, B, H, W, C / 4);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,145 @@
+"""ctypes binding of libfcvsr_hip.so (C ABI declared in include/fcvsr_hip.h).
+
+PyTorch is used only as the owner of device memory and streams: tensors are handed to the library as raw device
+pointers + strides (``fcvsr_view``) and every call enqueues on ``torch.cuda.current_stream()``.
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfcvsr_hip.so")
+
+F32, BF16, F16 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_PRELU = 0, 1, 2, 3
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+
+
+class View(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("sb", C.c_int64), ("sy", C.c_int64), ("sx", C.c_int64), ("sc", C.c_int64),
+                ("c", C.c_int32), ("dtype", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("n_src", C.c_int32), ("src", View * 3), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("cout", C.c_int32), ("weight", C.c_void_p), ("cout_pad", C.c_int32), ("bias", C.c_void_p),
+                ("act", C.c_int32), ("slope", C.c_float), ("slope_ptr", C.c_void_p), ("n_res", C.c_int32),
+                ("res", View * 2), ("res_scale", C.c_float * 2), ("dst", View), ("pixel_shuffle", C.c_int32)]
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+# name -> argtypes (restype is always int unless listed in _RESTYPES)
+_VP, _I, _I64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_PV = C.POINTER(View)
+SIGNATURES = {
+    "fcvsr_last_error": [],
+    "fcvsr_abi_version": [],
+    "fcvsr_device_count": [],
+    "fcvsr_conv2d": [C.POINTER(ConvDesc), _VP],
+    "fcvsr_rfft2": [_PV, _I, _I, _I, _I, _VP, _I64, _I, _I, _VP],
+    "fcvsr_irfft2": [_VP, _I64, _I, _I, _I, _I, _I, _I, _VP, _VP, _PV, _VP],
+    "fcvsr_corr_lookup": [_VP, _VP, _I64, _I, _I, _I, _I, _I, _PV, _VP],
+    "fcvsr_channel_sum": [_PV, _I, _I, _I, _VP, _VP, _I64, _VP],
+    "fcvsr_ca_gate": [_VP, _F, _VP, _VP, _I, _I, _I, _VP, _VP],
+    "fcvsr_convblk_tail": [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _I64, _I, _I, _I, _I, _VP],
+    "fcvsr_warp": [_PV, _PV, _I, _I, _I, _PV, _VP],
+    "fcvsr_sac_v": [_PV, _PV, _I, _I, _I, _PV, _VP],
+    "fcvsr_sac_h": [_PV, _PV, _PV, _F, _I, _I, _I, _PV, _VP],
+    "fcvsr_divenh": [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _F, _VP, _VP, _VP, _VP, _I64, _I, _I, _I, _I, _VP],
+    "fcvsr_scale_add": [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP],
+    "fcvsr_gc_context": [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _I64, _VP],
+    "fcvsr_gc_apply": [_VP, _VP, _VP, _VP, _F, _I, _I, _I, _I, _VP],
+    "fcvsr_xscale": [_VP, _VP, _F, _VP, _VP, _VP, _I, _I, _I, _I, _VP],
+    "fcvsr_pixel_shuffle": [_VP, _VP, _I, _I, _I, _I, _VP],
+    "fcvsr_bilinear_up4": [_PV, _I, _I, _I, _PV, _VP],
+}
+_RESTYPES = {"fcvsr_last_error": C.c_char_p}
+
+
+def lib() -> C.CDLL:
+    """Load the shared library (built by ``fcvsr_amd.build``).  Raises if it is absent: there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError(f"{LIB_PATH} not found: run `python -m fcvsr_amd.build` (hipcc, gfx950). "
+                           "fcvsr_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, C.c_int)
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().fcvsr_last_error()
+        raise HipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def view(t: torch.Tensor) -> View:
+    """View of a 4-D tensor whose logical dims are (b, y, x, c) with arbitrary strides (zero-copy)."""
+    assert t.dim() == 4, t.shape
+    sb, sy, sx, sc = t.stride()
+    return View(t.data_ptr(), sb, sy, sx, sc, t.shape[3], _DT[t.dtype])
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """(Cout, Cin, kh, kw) -> [kh*kw][Cin][cout_pad] f32, cout padded to a multiple of 16 (zero rows)."""
+    cout, cin, kh, kw = w.shape
+    cp = (cout + 15) // 16 * 16
+    out = torch.zeros(kh * kw, cin, cp, dtype=torch.float32, device=w.device)
+    out[:, :, :cout] = w.detach().float().permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)
+    return out.contiguous()
+
+
+def conv2d(srcs: Sequence[torch.Tensor], wpacked: torch.Tensor, ksize: int, cout: int, dst: torch.Tensor, *,
+           bias: Optional[torch.Tensor] = None, stride: int = 1, act: int = ACT_NONE, slope: float = 0.0,
+           slope_t: Optional[torch.Tensor] = None, res: Sequence[torch.Tensor] = (),
+           res_scale: Sequence[float] = (), pixel_shuffle: bool = False) -> torch.Tensor:
+    """srcs / res / dst are (b,y,x,c)-ordered tensors (any strides)."""
+    d = ConvDesc()
+    d.n_src = len(srcs)
+    for i, s in enumerate(srcs):
+        d.src[i] = view(s)
+    d.B, d.H, d.W = srcs[0].shape[0], srcs[0].shape[1], srcs[0].shape[2]
+    d.kh = d.kw = ksize
+    d.stride = stride
+    d.pad = ksize // 2
+    d.cout = cout
+    d.weight = wpacked.data_ptr()
+    d.cout_pad = wpacked.shape[-1]
+    cin = sum(s.shape[3] for s in srcs)
+    assert wpacked.shape[0] == ksize * ksize and wpacked.shape[1] == cin, (wpacked.shape, ksize, cin)
+    d.bias = ptr(bias)
+    d.act = act
+    d.slope = slope
+    d.slope_ptr = ptr(slope_t)
+    d.n_res = len(res)
+    for i, r in enumerate(res):
+        d.res[i] = view(r)
+        d.res_scale[i] = res_scale[i] if i < len(res_scale) else 1.0
+    d.dst = view(dst)
+    d.pixel_shuffle = int(pixel_shuffle)
+    check(lib().fcvsr_conv2d(C.byref(d), stream_ptr()), "fcvsr_conv2d")
+    return dst

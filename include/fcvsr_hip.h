@@ -1,0 +1,147 @@
+/*
+ * fcvsr_hip.h - C ABI of libfcvsr_hip.so: the MI355X (gfx950) hot path of FCVSR's per-frame forward.
+ *
+ * The reference (QZ1-boy/FCVSR) has no FFI/plugin boundary: its hot path is the Python method
+ * GShiftNet_S.forward / GShiftNet.forward (CVSR_train/arch/CVSR_freq.py:2611-2646, :2688-2756) built from
+ * stock torch ops.  The drop-in seam is therefore the Python nn.Module (fcvsr_amd/arch/CVSR_freq.py);
+ * *below* that seam every arithmetic step is one of the entry points declared here.  Each entry point cites
+ * the reference function(s) it replaces.  INTEGRATION.md shows the ctypes binding a reference maintainer adds.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all pointers are DEVICE pointers (HBM) unless named host_*;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue, never synchronise;
+ *  - every function returns 0 on success, a negative FCVSR_E_* code on bad arguments, or a positive
+ *    hipError_t when a launch fails; fcvsr_last_error() returns a human-readable message (thread-local);
+ *  - activations are described by `fcvsr_view`: a strided 4-D (b,y,x,c) window into a buffer, so NCHW boundary
+ *    tensors, NHWC internal tensors, channel slices and channel concatenations need no copies.
+ *    Internal layout is NHWC (channels innermost) so that a pixel's channels are one contiguous HBM segment.
+ */
+#ifndef FCVSR_HIP_H
+#define FCVSR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FCVSR_ABI_VERSION 1
+
+enum { FCVSR_E_ARG = -1, FCVSR_E_UNSUPPORTED = -2, FCVSR_E_NOGPU = -3 };
+enum { FCVSR_F32 = 0, FCVSR_BF16 = 1, FCVSR_F16 = 2 };
+enum { FCVSR_ACT_NONE = 0, FCVSR_ACT_RELU = 1, FCVSR_ACT_LEAKY = 2, FCVSR_ACT_PRELU = 3 };
+
+/* strided (b,y,x,c) window; strides in ELEMENTS of `dtype`; ptr already points at element (0,0,0,0) */
+typedef struct fcvsr_view {
+  void*   ptr;
+  int64_t sb, sy, sx, sc;
+  int32_t c;      /* number of channels in this window */
+  int32_t dtype;  /* FCVSR_F32 | FCVSR_BF16 | FCVSR_F16 */
+} fcvsr_view;
+
+/* One 2-D convolution with fused epilogue.  Replaces nn.Conv2d call sites of the path
+ * (CVSR_freq.py:2589 feat_extract, :1371-1396 convfuse/convcorr/convcrt, :344-357 ConvBlk convs, :1409-1416
+ * conv_KP/F, :1430 conv3, :2594-2609 rconcat/upconv/conv_last0, :705-803 RCB/BlockRCB/SCGroupbk convs) together with
+ * the elementwise ops the reference launches around them (bias, ReLU/LeakyReLU/PReLU, residual adds,
+ * torch.cat of inputs, nn.PixelShuffle(2) of the output).
+ *   dst = PS?( act(conv(cat(src[0..n_src)), W) + bias) + sum_i res_scale[i]*res[i] )
+ */
+typedef struct fcvsr_conv_desc {
+  int32_t     n_src;          /* 1..3 inputs concatenated along channels (torch.cat(dim=1)) */
+  fcvsr_view  src[3];
+  int32_t     B, H, W;        /* input spatial size */
+  int32_t     kh, kw, stride, pad;
+  int32_t     cout;
+  const void* weight;         /* packed by fcvsr_pack_conv_weight layout: [kh*kw][cin_total][cout_pad] (f32) */
+  int32_t     cout_pad;       /* row length of packed weight (multiple of 16) */
+  const float* bias;          /* cout floats or NULL */
+  int32_t     act;            /* FCVSR_ACT_* */
+  float       slope;          /* LEAKY slope */
+  const float* slope_ptr;     /* PRELU: device pointer to the scalar slope (nn.PReLU(), :2590) */
+  int32_t     n_res;          /* 0..2 residual inputs at OUTPUT (pre-shuffle) resolution with cout channels */
+  fcvsr_view  res[2];
+  float       res_scale[2];
+  fcvsr_view  dst;            /* output window; if pixel_shuffle: (2*Ho, 2*Wo) spatial, cout/4 channels */
+  int32_t     pixel_shuffle;  /* 0/1: out[c,2h+i,2w+j] = conv[4c+2i+j,h,w] (:2633-2642) */
+} fcvsr_conv_desc;
+
+const char* fcvsr_last_error(void);
+int  fcvsr_abi_version(void);
+/* number of HIP devices visible (0 when there is no GPU); never throws */
+int  fcvsr_device_count(void);
+
+/* direct (VALU, f32) convolution: any kernel size / channel count; used for skinny layers and as the exact-f32 path */
+int fcvsr_conv2d(const fcvsr_conv_desc* d, void* stream);
+
+/* ---- frequency transforms: torch.fft.rfft2 / irfft2 (norm='backward') of NHWC channel groups -------------
+ * Spectrum layout: buffer [B][H][Wf][pix_stride] with Wf=W/2+1; channel c of the group has its imaginary part at
+ * channel im_off+c and its real part at re_off+c (the reference packs [imag, real], CVSR_freq.py:1456-1465).
+ * fcvsr_rfft2 : real src (B,H,W,n) -> spectrum            (replaces :1452-1465 and the fftn of :2082-2084)
+ * fcvsr_irfft2: spectrum (optionally multiplied by a real (H,Wf) mask per group of `mask_every` channels...)
+ *               -> real dst (B,H,W,n), scaled 1/(H*W)     (replaces :1497-1505 and the ifftn(...).real of :2085-2090)
+ *   work: scratch buffer of the same size as the spectrum region used (B*H*Wf*2n floats), or NULL to run the
+ *   column pass in place (destroys the spectrum).  mask: (H,Wf) floats or NULL.
+ */
+int fcvsr_rfft2(const fcvsr_view* src, int B, int H, int W, int n,
+                float* spec, int64_t pix_stride, int im_off, int re_off, void* stream);
+int fcvsr_irfft2(const float* spec, int64_t pix_stride, int im_off, int re_off, int B, int H, int W, int n,
+                 const float* mask, float* work, const fcvsr_view* dst, void* stream);
+
+/* ---- MGAAbk pieces (CVSR_freq.py:1365-1547) ---------------------------------------------------------------- */
+/* CorrBlock lookup on the integer grid (:1279-1337): x1f,x2f NHWC (B,H,Wf,C) with pixel stride
+ * pix_stride (floats); dst (B,H,Wf,>=81); channels beyond (2r+1)^2 are zero-filled */
+int fcvsr_corr_lookup(const float* x1f, const float* x2f, int64_t pix_stride, int B, int H, int Wf, int C, int radius,
+                      const fcvsr_view* dst, void* stream);
+/* per-(b,c) sums over (y,x) of a view, deterministic two-stage: out[b][c] (f32).  scratch: B*nblk*C floats */
+int fcvsr_channel_sum(const fcvsr_view* src, int B, int H, int W, float* out, float* scratch, int64_t scratch_elems,
+                      void* stream);
+/* CALayer gate (:1812-1828): gate[b][c] = sigmoid(W2 relu(W1 (sum[b][:]*inv_hw)));  W1 (cr x c), W2 (c x cr) row-major */
+int fcvsr_ca_gate(const float* sum, float inv_hw, const float* w1, const float* w2, int B, int c, int cr,
+                  float* gate, void* stream);
+/* ConvBlk tail + similarity + complex packing (:344-357 `CA(out)+out`, :1495-1498):
+ *   o = (u*gate + u) * sim;  u,sim (Bn,H,Wf,4) with u's batch = dir*B+b and sim's batch = b;
+ *   writes re (o[0:2]) to spec channel re_off + 2*g + j and im (o[2:4]) to im_off + 2*g + j, g = dir*A + i */
+int fcvsr_convblk_tail(const float* u, const float* gate, const float* sim, int B, int ndir, int H, int Wf,
+                       float* spec, int64_t pix_stride, int re_off, int im_off, int g_stride, int g0, void* stream);
+/* flow_warp (:1188-1227): bilinear, zeros padding, sample at (x+off[0], y+off[1]) */
+int fcvsr_warp(const fcvsr_view* src, const fcvsr_view* off, int B, int H, int W, const fcvsr_view* dst, void* stream);
+/* SAC (:1253-1276) vertical pass: v = sum_t s[clamp(y+t-1)] * k1[c*3+t] */
+int fcvsr_sac_v(const fcvsr_view* s, const fcvsr_view* k1, int B, int H, int W, const fcvsr_view* dst, void* stream);
+/* SAC horizontal pass (kernel1 again, :1273) + IAC residual and LeakyReLU(0.1) (:1243-1248) */
+int fcvsr_sac_h(const fcvsr_view* v, const fcvsr_view* k1, const fcvsr_view* feat_in, float slope,
+                int B, int H, int W, const fcvsr_view* dst, void* stream);
+
+/* ---- MultiFreq_Refinment pieces (CVSR_freq.py:2104-2133, :2201-2254) ---------------------------------------- */
+/* DivEnh expressions, i==0 (first=1): t=f-mean_f; e1=0.2*a*t*f+b*f.  i>0: t=f-s_f+0.2*s_o; e1 as above;
+ * e2=0.2*a*s_o*f+b*f.   mode 0: write per-(b,c) sums of e1,e2 to sums[2][B][C] (two-stage, deterministic);
+ * mode 1: o=e1*g1(+e2*g2); s_f+=f; s_o+=o (in place). All tensors dense NHWC (B,H,W,C). */
+int fcvsr_divenh(int mode, int first, const float* f, float* s_f, float* s_o, const float* a, const float* b,
+                 const float* mean_f_sum, float inv_hw, const float* g1, const float* g2,
+                 float* sums, float* scratch, int64_t scratch_elems, int B, int H, int W, int C, void* stream);
+/* out = z*gate[b][c] + x   (final CALayer of MFFR, :2229-2230) */
+int fcvsr_scale_add(const float* z, const float* gate, const float* x, float* out, int B, int H, int W, int C,
+                    void* stream);
+
+/* ---- SCNetbk pieces (CVSR_freq.py:657-822) ------------------------------------------------------------------- */
+/* ContextBlock (:657-701): add[b][c] = W2 lrelu0.2(W1 ctx), ctx = sum_p r[p]*softmax_p(r[p].wmask)
+ *   scratch: B*nblk*(C+2) floats */
+int fcvsr_gc_context(const float* r, const float* wmask, const float* w1, const float* w2, int B, int H, int W, int C,
+                     float* add, float* scratch, int64_t scratch_elems, void* stream);
+/* RCB tail (:722-725): out = lrelu0.2(r + add[b][c]) + z */
+int fcvsr_gc_apply(const float* r, const float* add, const float* z, float* out, float slope,
+                   int B, int H, int W, int C, void* stream);
+/* BlockRCB cross-scale sum (:766-777): out = x + r_scale*r + avgpool2(dn) + bilinear_up2(up); dn/up may be NULL.
+ * dn is (B,2H,2W,C), up is (B,H/2,W/2,C) */
+int fcvsr_xscale(const float* x, const float* r, float r_scale, const float* dn, const float* up, float* out,
+                 int B, int H, int W, int C, void* stream);
+
+/* ---- tail ------------------------------------------------------------------------------------------------------ */
+/* nn.PixelShuffle(2) of a dense NHWC tensor (B,H,W,C) -> (B,2H,2W,C/4) (:2634-2635) */
+int fcvsr_pixel_shuffle(const float* src, float* dst, int B, int H, int W, int C, void* stream);
+/* F.interpolate(scale_factor=4, bilinear, align_corners=False) (:2644): src view (B,H,W,c) -> dst view (B,4H,4W,c) */
+int fcvsr_bilinear_up4(const fcvsr_view* src, int B, int H, int W, const fcvsr_view* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCVSR_HIP_H */

@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Benchmark of the FCVSR per-frame forward hot path on MI355X (contract: see the task prompt / DESIGN.md section 6).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one pass of the hot path (model(lrs)) over one batch of `--batch` synthetic 7-frame windows of
+180x320 LR frames (4x -> 720x1280), inputs resident in HBM before the timed region.  Clips are independent, so ranks
+run disjoint clips with no data-path collective ("weak" scaling); value = frames all ranks produced / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+def conv_flops_live(model_name: str, H: int, W: int) -> float:
+    """Live conv FLOPs (2*MAC) per output frame, Y model (552.33 G (S) / 1294.58 G (full) at 180x320)."""
+    per_px = {"S": 552.33e9, "full": 1294.58e9}[model_name] / (180 * 320)
+    return per_px * H * W
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads() -> int:
+    """CPU threads this process may actually use (cgroup/affinity aware), capped at 16 (the GPU box's per-GPU share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1, help="7-frame windows per step per GPU")
+    ap.add_argument("--model", choices=["S", "full"], default="S")
+    ap.add_argument("--height", type=int, default=180)
+    ap.add_argument("--width", type=int, default=320)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from fcvsr_amd import hip
+    from fcvsr_amd.arch import CVSR_freq as A
+    from fcvsr_amd.arch.schema import state_dict_shapes
+    from fcvsr_amd.weights import synthetic_state_dict
+
+    ctor = "GShiftNet_S" if args.model == "S" else "GShiftNet"
+    sd = synthetic_state_dict(state_dict_shapes(ctor), gain=0.5)
+    model = getattr(A, ctor)()
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    B, H, W = args.batch, args.height, args.width
+    rs = np.random.RandomState(1 + rank)                      # different clips per rank, same weights
+    x = torch.from_numpy(rs.rand(B, 7, 1, H, W).astype(np.float32)).to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f"model {ctor} on {dev}, input {tuple(x.shape)}; warmup {args.warmup}")
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            y = model(x)
+            torch.cuda.synchronize()
+            log("warmup step done")
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = model(x)
+        barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(y).all())
+    log(f"timed {args.steps} steps in {dt:.3f} s")
+    frames = world * B * args.steps
+    fps = frames / dt
+
+    roofline = None
+    if not args.no_roofline:
+        # Dominant kernel class = the convolution kernel (>= 98 % of FLOPs).  One extra instrumented step: every conv launch
+        # is bracketed by HIP events on the launch stream; achieved = sum(algorithmic FLOPs) / sum(durations).
+        hip.PROFILE = []
+        with torch.no_grad():
+            model(x)
+        torch.cuda.synchronize()
+        recs = hip.PROFILE
+        hip.PROFILE = None
+        tot_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+        tot_fl = sum(f for _, _, f in recs)
+        dtype = hip.COMPUTE_DTYPE
+        peak = PEAK_TFLOPS[dtype]
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        roofline = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 5), "traffic": None, "kernel": hip.DOMINANT_KERNEL,
+                    "launches_per_step": len(recs), "avg_launch_us": round(tot_ms * 1e3 / max(1, len(recs)), 2),
+                    "flops_per_step": tot_fl}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import fcvsr_oracle as O                  # CPU baseline leg only: the oracle as a timed "port"
+        ncpu = host_threads()
+        torch.set_num_threads(ncpu)
+        log(f"cpu baseline: oracle on {ncpu} threads")
+        xc = x[:1].cpu()
+        with torch.no_grad():
+            O.forward(sd, xc)
+            ts = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                O.forward(sd, xc)
+                ts.append(time.perf_counter() - t1)
+                log(f"cpu baseline run {ts[-1]:.2f} s")
+        cpu = {"value": round(1.0 / float(np.median(ts)), 4), "unit": "frames/s", "cores": torch.get_num_threads(),
+               "kind": "port", "sample": f"3 forwards of one {H}x{W} 7-frame window (median), fp32 torch CPU oracle"}
+
+    if rank == 0:
+        line = {
+            "metric": "SR frames/sec (7-frame window, 4x 180x320->720x1280)", "value": round(fps, 3),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": hip.COMPUTE_DTYPE, "data": "synthetic",
+            "config": {"workload": f"FCVSR-{args.model} 4x inference, {B}x7x{H}x{W} -> {4*H}x{4*W} synthetic clips, "
+                                   f"random-init (key-seeded) weights", "batch_per_gpu": B, "parallelism": f"clip-dp{world}"},
+            "frames_per_sec_per_gpu": round(fps / world, 3),
+            "conv_tflops_end_to_end": round(fps * conv_flops_live(args.model, H, W) / 1e12, 3),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

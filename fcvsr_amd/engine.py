@@ -1,0 +1,433 @@
+"""Host-side orchestration of the FCVSR forward on one MI355X: the sequence of libfcvsr_hip.so calls that realises
+``GShiftNet_S.forward`` / ``GShiftNet.forward`` (reference CVSR_train/arch/CVSR_freq.py:2611-2646, :2688-2756).
+
+Layout in HBM: every internal activation is NHWC f32 (``(B,H,W,C)`` contiguous, channels innermost); channel slices and
+concatenations are expressed as strided views (no copies).  The NCHW boundary tensors are read / written in place through
+strided views as well (first conv reads the caller's ``(B,7,C,H,W)`` frames directly, the last conv writes ``(B,C,4H,4W)``).
+torch is used for device memory (caching allocator), streams and the one-time weight re-packing; no torch arithmetic
+runs in the per-frame path.
+
+Dead compute of the reference that cannot affect outputs is skipped: ``corrb``, the ``F2`` half of
+``MGAA.F[1]``, the zero flow channels, ``DivEnh.Conv``, and every visualisation / host sync inside forward.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import weakref
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import hip
+from .hip import ACT_LEAKY, ACT_NONE, ACT_PRELU, ACT_RELU, check, lib, ptr, stream_ptr, view
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Band masks (host-side constant tables, cached per (Q,H,W); reference Split_freq.generate_freq_mask :2016-2049 +
+# bicubic Resize :2078, folded into the symmetrised half-spectrum form of SURVEY A.4)
+# --------------------------------------------------------------------------------------------------------------
+_MASKS: Dict[Tuple[int, int, int], torch.Tensor] = {}
+
+
+def band_masks_half(Q: int, H: int, W: int) -> torch.Tensor:
+    """(Q,H,Wf) f32 CPU tensor M_sym with  Re(ifft2(ifftshift(fftshift(fft2 x) * mask_q))) == irfft2(rfft2(x) * M_sym[q])."""
+    key = (Q, H, W)
+    if key not in _MASKS:
+        n = 1024
+        step = math.sqrt((n / 2) ** 2 + (n / 2) ** 2) / Q
+        d2 = (np.arange(-(n // 2), n - n // 2, 1) ** 2).astype(np.float64)
+        r2 = np.power(np.sqrt(d2[:, None] + d2[None, :]), 2)
+        bands: List[torch.Tensor] = []
+        for q in range(Q):
+            g = torch.from_numpy(np.exp(-r2 / (2 * ((step * (q + 1)) ** 2)))).float()
+            for prev in bands:
+                g = g - prev
+            bands.append(g)
+        m = torch.stack(bands, 0)
+        m = torch.nn.functional.interpolate(m[None], size=[H, W], mode="bicubic", align_corners=False,
+                                            antialias=False)[0]
+        M = torch.fft.ifftshift(m, dim=(1, 2))
+        Mneg = torch.roll(torch.flip(M, dims=(1, 2)), shifts=(1, 1), dims=(1, 2))
+        _MASKS[key] = (0.5 * (M + Mneg))[:, :, : W // 2 + 1].contiguous()
+    return _MASKS[key]
+
+
+class Engine:
+    def __init__(self, model):
+        self._model = weakref.ref(model)
+        self._packed: Dict[str, torch.Tensor] = {}
+        self._versions: Optional[Tuple] = None
+        self._dev_masks: Dict[Tuple, torch.Tensor] = {}
+        self._par: Dict[str, torch.Tensor] = {}
+        self._warned = False
+        self.taps: Optional[dict] = None       # set to a dict to record NCHW copies of intermediate results (tests)
+
+    # ---------------------------------------------------------------------------------------------- weights
+    def _refresh(self, dev):
+        m = self._model()
+        sd = {k: v for k, v in m.named_parameters()}
+        ver = tuple((k, v._version, v.data_ptr()) for k, v in sd.items()) + (str(dev),)
+        if ver == self._versions:
+            return
+        P: Dict[str, torch.Tensor] = {}
+        n, A = m.n_feats, m.ACNum
+        for k, v in sd.items():
+            if v.device != dev:
+                raise RuntimeError(f"parameter {k} is on {v.device}, input on {dev}: call model.to(device) first")
+            if k.endswith(".weight") and v.dim() == 4 and ".Conv." not in k:
+                if k == "MGAA.F.1.weight":
+                    rows = torch.cat([torch.arange(i * 6 * n, i * 6 * n + 3 * n) for i in range(A)]).to(dev)
+                    P[k] = hip.pack_conv_weight(v.detach()[rows])
+                    P["MGAA.F.1.bias"] = sd["MGAA.F.1.bias"].detach()[rows].contiguous()
+                elif k == "MGAA.convcorr.0.weight":
+                    w = v.detach()
+                    wp = torch.zeros(w.shape[0], 2 * n + 84, 1, 1, device=dev, dtype=torch.float32)
+                    wp[:, : 2 * n + 81] = w[:, : 2 * n + 81]      # drop the 2 zero-flow inputs, pad corr 81 -> 84
+                    P[k] = hip.pack_conv_weight(wp)
+                else:
+                    P[k] = hip.pack_conv_weight(v.detach())
+        self._packed = P
+        self._par = sd
+        self._versions = ver
+
+    def _mask(self, Q, H, W, dev):
+        key = (Q, H, W, str(dev))
+        if key not in self._dev_masks:
+            self._dev_masks[key] = band_masks_half(Q, H, W).to(dev)
+        return self._dev_masks[key]
+
+    # ---------------------------------------------------------------------------------------------- helpers
+    def _conv(self, name, srcs, dst, *, k=None, stride=1, act=ACT_NONE, slope=0.0, slope_t=None, res=(), res_scale=(),
+              ps=False, bias=True, cout=None):
+        m = self._model()
+        w = self._packed[name + ".weight"]
+        par = self._par
+        if name == "MGAA.F.1":
+            b = self._packed["MGAA.F.1.bias"]
+        else:
+            b = par.get(name + ".bias") if bias else None
+        wt = par[name + ".weight"]
+        ksz = wt.shape[-1] if k is None else k
+        co = (wt.shape[0] if cout is None else cout)
+        return hip.conv2d(srcs, w, ksz, co, dst, bias=b, stride=stride, act=act, slope=slope, slope_t=slope_t, res=res,
+                          res_scale=res_scale, pixel_shuffle=ps)
+
+    def _tap(self, name, t_nhwc):
+        if self.taps is not None:
+            self.taps[name] = t_nhwc.permute(0, 3, 1, 2).contiguous().clone()
+
+    @staticmethod
+    def _new(dev, *shape):
+        return torch.empty(*shape, device=dev, dtype=torch.float32)
+
+    def _channel_sum(self, t):
+        B, H, W, Cc = t.shape
+        nblk = (H * W + 1023) // 1024
+        out = self._new(t.device, B, Cc)
+        scratch = self._new(t.device, B * nblk * Cc)
+        v = view(t)
+        check(lib().fcvsr_channel_sum(C.byref(v), B, H, W, out.data_ptr(), scratch.data_ptr(), scratch.numel(),
+                                      stream_ptr()), "fcvsr_channel_sum")
+        return out
+
+    def _ca_gate(self, sums, inv_hw, prefix, Bn, c):
+        par = self._par
+        w1, w2 = par[prefix + ".conv_du.0.weight"], par[prefix + ".conv_du.2.weight"]
+        gate = self._new(sums.device, Bn, c)
+        check(lib().fcvsr_ca_gate(sums.data_ptr(), inv_hw, w1.data_ptr(), w2.data_ptr(), Bn, c, w1.shape[0],
+                                  gate.data_ptr(), stream_ptr()), "fcvsr_ca_gate")
+        return gate
+
+    # ---------------------------------------------------------------------------------------------- MGAAbk
+    def _mgaa(self, x1, x2, x3, tag):
+        """x1,x2,x3: (B,H,W,n) views (reference MGAAbk.forward, CVSR_freq.py:1442-1547)."""
+        m = self._model()
+        n, A = m.n_feats, m.ACNum
+        dev = x1.device
+        B, H, W, _ = x1.shape
+        Wf = W // 2 + 1
+        L = lib()
+        st = stream_ptr()
+        par = self._par
+
+        spec = self._new(dev, B, H, Wf, 6 * n)                   # [x1f | x2f | x3f], each [imag(n), real(n)]
+        for i, xi in enumerate((x1, x2, x3)):
+            v = view(xi)
+            check(L.fcvsr_rfft2(C.byref(v), B, H, W, n, spec[..., 2 * n * i:].data_ptr(), 6 * n, 0, n, st),
+                  "fcvsr_rfft2")
+        x1f, x2f, x3f = spec[..., :2 * n], spec[..., 2 * n:4 * n], spec[..., 4 * n:]
+
+        # offset spectra: (x?f - x2f) + convfuse(cat[x?f, x2f]); batch index = dir*B + b
+        off = self._new(dev, 2 * B, H, Wf, 2 * n)
+        t0 = self._new(dev, B, H, Wf, 2 * n)
+        t1 = self._new(dev, B, H, Wf, 2 * n)
+        for d, xa in enumerate((x1f, x3f)):
+            self._conv("MGAA.convfuse.0", [xa, x2f], t0, act=ACT_RELU)
+            self._conv("MGAA.convfuse.2", [t0], t1, act=ACT_RELU)
+            self._conv("MGAA.convfuse.4", [t1], off[d * B:(d + 1) * B], res=[xa, x2f], res_scale=[1.0, -1.0])
+        s0 = self._new(dev, B, H, Wf, n)
+        sim = self._new(dev, B, H, Wf, 4)
+        self._conv("MGAA.convcrt.0", [x2f], s0, act=ACT_RELU)
+        self._conv("MGAA.convcrt.2", [s0], sim)
+
+        corr = self._new(dev, B, H, Wf, 84)                      # 81 live channels + 3 zero pad (16-byte pixels)
+        cv = view(corr)
+        check(L.fcvsr_corr_lookup(x1f.data_ptr(), x2f.data_ptr(), 6 * n, B, H, Wf, 2 * n, 4, C.byref(cv), st),
+              "fcvsr_corr_lookup")
+        c0 = self._new(dev, 2 * B, H, Wf, n)
+        c1 = self._new(dev, 2 * B, H, Wf, n)
+        off4 = self._new(dev, 2 * B, H, Wf, 4)
+        for d in range(2):
+            self._conv("MGAA.convcorr.0", [off[d * B:(d + 1) * B], corr], c0[d * B:(d + 1) * B], act=ACT_RELU)
+        self._conv("MGAA.convcorr.2", [c0], c1, act=ACT_RELU)
+        self._conv("MGAA.convcorr.4", [c1], off4)
+
+        # A multi-scale ConvBlk heads -> (real, imag) planes -> irfft2 -> pixel offsets
+        ospec = self._new(dev, B, H, Wf, 8 * A)                  # re: [0,4A), im: [4A,8A); channel = (dir*A+i)*2 + j
+        tt = self._new(dev, 2 * B, H, Wf, 4)
+        u = self._new(dev, 2 * B, H, Wf, 4)
+        for i in range(A):
+            pre = f"MGAA.MConvB.{i}"
+            self._conv(pre + ".conv1", [off4], tt, act=ACT_PRELU, slope_t=par[pre + ".relu.weight"])
+            self._conv(pre + ".conv2", [tt], u)
+            gate = self._ca_gate(self._channel_sum(u), 1.0 / (H * Wf), pre + ".CA", 2 * B, 4)
+            check(L.fcvsr_convblk_tail(u.data_ptr(), gate.data_ptr(), sim.data_ptr(), B, 2, H, Wf, ospec.data_ptr(),
+                                       8 * A, 0, 4 * A, A, i, st), "fcvsr_convblk_tail")
+        offsets = self._new(dev, B, H, W, 4 * A)
+        ov = view(offsets)
+        check(L.fcvsr_irfft2(ospec.data_ptr(), 8 * A, 4 * A, 0, B, H, W, 4 * A, None, None, C.byref(ov), st),
+              "fcvsr_irfft2")
+
+        # kernel predictor (only the F1 half of F[1] is ever read)
+        kp = self._new(dev, B, H, W, n)
+        k0 = self._new(dev, B, H, W, n)
+        K = self._new(dev, B, H, W, A * 3 * n)
+        self._conv("MGAA.conv_KP", [x2], kp)
+        self._conv("MGAA.F.0", [kp], k0)
+        self._conv("MGAA.F.1", [k0], K, cout=A * 3 * n)
+
+        # iterative alignment: warp -> SAC(kernel1 twice) -> + feat_in -> LeakyReLU(0.1)
+        al = self._new(dev, B, H, W, 2 * n)
+        s = self._new(dev, B, H, W, n)
+        vbuf = self._new(dev, B, H, W, n)
+        ping = [self._new(dev, B, H, W, n), self._new(dev, B, H, W, n)]
+        for d, fin in enumerate((x1, x3)):
+            cur = fin
+            fv = view(fin)
+            for i in range(A):
+                g = d * A + i
+                o_v = view(offsets[..., 2 * g:2 * g + 2])
+                k_v = view(K[..., i * 3 * n:(i + 1) * 3 * n])
+                dst = al[..., d * n:(d + 1) * n] if i == A - 1 else ping[i % 2]
+                cur_v, s_v, v_v, d_v = view(cur), view(s), view(vbuf), view(dst)
+                check(L.fcvsr_warp(C.byref(cur_v), C.byref(o_v), B, H, W, C.byref(s_v), st), "fcvsr_warp")
+                check(L.fcvsr_sac_v(C.byref(s_v), C.byref(k_v), B, H, W, C.byref(v_v), st), "fcvsr_sac_v")
+                check(L.fcvsr_sac_h(C.byref(v_v), C.byref(k_v), C.byref(fv), 0.1, B, H, W, C.byref(d_v), st),
+                      "fcvsr_sac_h")
+                cur = dst
+        out = self._new(dev, B, H, W, n)
+        self._conv("MGAA.conv3", [al], out, res=[x2])
+        if self.taps is not None:
+            self._tap(f"mgaa{tag}.off_f", off4[:B])
+            self._tap(f"mgaa{tag}.off_b", off4[B:])
+            self._tap(f"mgaa{tag}.sim", sim)
+            o = offsets.permute(0, 3, 1, 2).reshape(B, 2, A, 2, H, W)
+            self.taps[f"mgaa{tag}.offsets_f"] = o[:, 0].contiguous().clone()
+            self.taps[f"mgaa{tag}.offsets_b"] = o[:, 1].contiguous().clone()
+            self._tap(f"mgaa{tag}.al_f", al[..., :n])
+            self._tap(f"mgaa{tag}.al_b", al[..., n:])
+            self._tap(f"mgaa{tag}.out", out)
+        return out
+
+    # ---------------------------------------------------------------------------------------------- MFFR
+    def _mffr(self, x):
+        """MultiFreq_Refinment.forward (CVSR_freq.py:2201-2254) on dense NHWC x."""
+        m = self._model()
+        n, Q = m.n_feats, m.Freq_Inv
+        dev = x.device
+        B, H, W, _ = x.shape
+        Wf = W // 2 + 1
+        L = lib()
+        st = stream_ptr()
+        par = self._par
+        masks = self._mask(Q, H, W, dev)
+        spec = self._new(dev, B, H, Wf, 2 * n)
+        work = self._new(dev, B, H, Wf, 2 * n)
+        xv = view(x)
+        check(L.fcvsr_rfft2(C.byref(xv), B, H, W, n, spec.data_ptr(), 2 * n, 0, n, st), "fcvsr_rfft2")
+        bands = self._new(dev, Q, B, H, W, n)
+        for q in range(Q):
+            bv = view(bands[q])
+            check(L.fcvsr_irfft2(spec.data_ptr(), 2 * n, 0, n, B, H, W, n, masks[q].data_ptr(), work.data_ptr(),
+                                 C.byref(bv), st), "fcvsr_irfft2")
+        freq = [bands[Q - 1 - i] for i in range(Q)]               # 'l2h' => reversed band list (:2204-2205)
+        s_f = self._new(dev, B, H, W, n)
+        s_o = self._new(dev, B, H, W, n)
+        nblk = (H * W + 1023) // 1024
+        scratch = self._new(dev, 2 * B * nblk * n)
+        sums = self._new(dev, 2, B, n)
+        inv_hw = 1.0 / (H * W)
+        mean_sum = self._channel_sum(freq[0])
+        for i in range(Q):
+            pre = f"MFFRblock.DivEnh_block.{i}"
+            a, b = par[pre + ".a"], par[pre + ".b"]
+            first = 1 if i == 0 else 0
+            check(L.fcvsr_divenh(0, first, freq[i].data_ptr(), s_f.data_ptr(), s_o.data_ptr(), a.data_ptr(),
+                                 b.data_ptr(), mean_sum.data_ptr(), inv_hw, None, None, sums.data_ptr(),
+                                 scratch.data_ptr(), scratch.numel(), B, H, W, n, st), "fcvsr_divenh(reduce)")
+            g1 = self._ca_gate(sums[0], inv_hw, pre + ".ca", B, n)
+            g2 = self._ca_gate(sums[1], inv_hw, pre + ".ca", B, n) if i > 0 else None
+            check(L.fcvsr_divenh(1, first, freq[i].data_ptr(), s_f.data_ptr(), s_o.data_ptr(), a.data_ptr(),
+                                 b.data_ptr(), mean_sum.data_ptr(), inv_hw, g1.data_ptr(), ptr(g2), None, None, 0,
+                                 B, H, W, n, st), "fcvsr_divenh(apply)")
+        g = self._ca_gate(self._channel_sum(s_o), inv_hw, "MFFRblock.ca", B, n)
+        out = self._new(dev, B, H, W, n)
+        check(L.fcvsr_scale_add(s_o.data_ptr(), g.data_ptr(), x.data_ptr(), out.data_ptr(), B, H, W, n, st),
+              "fcvsr_scale_add")
+        if self.taps is not None:
+            self.taps["mffr.bands"] = torch.stack([f.permute(0, 3, 1, 2) for f in freq], 1).contiguous().clone()
+            self._tap("mffr.out", out)
+        return out
+
+    # ---------------------------------------------------------------------------------------------- SCNetbk
+    def _block_rcb(self, pre, xs):
+        """BlockRCB.forward (CVSR_freq.py:766-777) on the 3-level pyramid xs (dense NHWC)."""
+        m = self._model()
+        n = m.n_feats
+        L = lib()
+        st = stream_ptr()
+        par = self._par
+        R = []
+        for x in xs:
+            dev = x.device
+            B, H, W, _ = x.shape
+            t1 = self._new(dev, B, H, W, 2 * n)
+            t2 = self._new(dev, B, H, W, n)
+            r1 = self._new(dev, B, H, W, n)
+            r = self._new(dev, B, H, W, n)
+            self._conv(pre + ".body.0", [x], t1, act=ACT_LEAKY, slope=0.1)
+            self._conv(pre + ".body.2", [t1], t2)
+            self._conv(pre + ".RCB.body.0", [t2], r1, act=ACT_LEAKY, slope=0.2)
+            self._conv(pre + ".RCB.body.2", [r1], r)
+            add = self._new(dev, B, n)
+            nblk = (H * W + 255) // 256
+            scratch = self._new(dev, B * nblk * (n + 2))
+            check(L.fcvsr_gc_context(r.data_ptr(), par[pre + ".RCB.gcnet.conv_mask.weight"].data_ptr(),
+                                     par[pre + ".RCB.gcnet.channel_add_conv.0.weight"].data_ptr(),
+                                     par[pre + ".RCB.gcnet.channel_add_conv.2.weight"].data_ptr(), B, H, W, n,
+                                     add.data_ptr(), scratch.data_ptr(), scratch.numel(), st), "fcvsr_gc_context")
+            Rl = self._new(dev, B, H, W, n)
+            check(L.fcvsr_gc_apply(r.data_ptr(), add.data_ptr(), t2.data_ptr(), Rl.data_ptr(), 0.2, B, H, W, n, st),
+                  "fcvsr_gc_apply")
+            R.append(Rl)
+        dn = [self._conv(pre + ".down.0", [R[l]], torch.empty_like(R[l])) for l in (0, 1)]
+        up = [self._conv(pre + ".up.0", [R[l]], torch.empty_like(R[l])) for l in (1, 2)]
+        outs = []
+        for l, x in enumerate(xs):
+            B, H, W, _ = x.shape
+            y = torch.empty_like(x)
+            rs = 2.0 if l in (0, 2) else 1.0
+            d = dn[l - 1] if l >= 1 else None
+            u = up[l] if l <= 1 else None
+            check(L.fcvsr_xscale(x.data_ptr(), R[l].data_ptr(), rs, ptr(d), ptr(u), y.data_ptr(), B, H, W, n, st),
+                  "fcvsr_xscale")
+            outs.append(y)
+        return outs
+
+    def _scnet(self, xs):
+        m = self._model()
+        cur = xs
+        for g in range(m.SCGroupN):
+            t = cur
+            for k in range(3):
+                t = self._block_rcb(f"recorb1.body.{g}.body.{k}", t)
+            last = g == m.SCGroupN - 1
+            nxt = []
+            for l in range(3):
+                y = torch.empty_like(cur[l])
+                res = [cur[l], xs[l]] if last else [cur[l]]       # fold SCNetbk's outer skip into the last group conv
+                self._conv(f"recorb1.body.{g}.conv", [t[l]], y, res=res)
+                nxt.append(y)
+            cur = nxt
+        return cur
+
+    # ---------------------------------------------------------------------------------------------- top level
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        m = self._model()
+        if torch.is_grad_enabled() and not self._warned and any(p.requires_grad for p in m.parameters()):
+            import warnings
+            warnings.warn("fcvsr_amd: backward through the HIP path is not implemented yet; the output is detached "
+                          "(wrap inference in torch.no_grad() to silence this)")
+            self._warned = True
+        with torch.no_grad():
+            return self._forward_checked(x, m)
+
+    def _forward_checked(self, x, m):
+        if x.dim() != 5:
+            raise ValueError(f"expected (B,T,C,H,W) input, got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("fcvsr_amd runs on MI355X only: move the model and the input to a HIP device "
+                               "(there is no CPU fallback)")
+        B, T, Cimg, H, W = x.shape
+        if T != m._in_frames or Cimg != m._img_ch:
+            raise ValueError(f"expected {m._in_frames} frames of {m._img_ch} channel(s), got T={T}, C={Cimg}")
+        if H % 4 or W % 4:
+            raise ValueError("H and W must be multiples of 4 (3-level pyramid, reference BlockRCB :766-777)")
+        dev = x.device
+        with torch.cuda.device(dev):
+            return self._forward(x.contiguous().float(), m, B, T, Cimg, H, W, dev)
+
+    def _forward(self, x, m, B, T, Cimg, H, W, dev):
+        self._refresh(dev)
+        n = m.n_feats
+        L = lib()
+        st = stream_ptr()
+        a_t = m.lrelu.weight
+        xin = x.view(B, T * Cimg, H, W).permute(0, 2, 3, 1)      # (b,y,x,c) strided view of the NCHW frames
+        feat = self._new(dev, B, H, W, 7 * n)
+        self._conv("feat_extract.0", [xin], feat)
+        self._tap("feat", feat)
+        f1, f2, f3 = feat[..., :3 * n], feat[..., 3 * n:4 * n], feat[..., 4 * n:]
+        a1 = self._mgaa(f1[..., :n], f1[..., n:2 * n], f1[..., 2 * n:], "1")
+        a3 = self._mgaa(f3[..., :n], f3[..., n:2 * n], f3[..., 2 * n:], "3")
+        a2 = self._mgaa(a1, f2, a3, "2")
+        d0 = self._mffr(a2)
+        d1 = self._new(dev, B, H // 2, W // 2, n)
+        d2 = self._new(dev, B, H // 4, W // 4, n)
+        self._conv("rconcat1", [d0], d1, stride=2)
+        self._conv("rconcat2", [d1], d2, stride=2)
+        o0, o1, o2 = self._scnet([d0, d1, d2])
+        self._tap("sc.o0", o0), self._tap("sc.o1", o1), self._tap("sc.o2", o2)
+
+        # pyramid fuse (:2633-2639); PReLU commutes with PixelShuffle (one shared scalar slope)
+        l3_1 = self._new(dev, B, H // 2, W // 2, n // 4)
+        self._conv("upconv1_L3", [o2], l3_1, act=ACT_PRELU, slope_t=a_t, ps=True)
+        l3_2 = self._new(dev, B, H, W, n // 16)
+        check(L.fcvsr_pixel_shuffle(l3_1.data_ptr(), l3_2.data_ptr(), B, H // 2, W // 2, n // 4, st),
+              "fcvsr_pixel_shuffle")
+        l2 = self._new(dev, B, H // 2, W // 2, n)
+        self._conv("upconv1_L2", [o1], l2, act=ACT_PRELU, slope_t=a_t)
+        l2p = self._new(dev, B, H, W, n // 4)
+        self._conv("upconv1_L2_2", [l2, l3_1], l2p, res=[l2], ps=True)
+        fz0 = self._new(dev, B, H, W, n)
+        fz = self._new(dev, B, H, W, n)
+        self._conv("upconv_fuse", [o0, l2p, l3_2], fz0)
+        self._conv("recorb0", [fz0], fz)
+        self._tap("fz", fz)
+
+        # up-sampler (:2641-2645)
+        u1 = self._new(dev, B, 2 * H, 2 * W, n)
+        self._conv("upconv1", [fz], u1, act=ACT_PRELU, slope_t=a_t, ps=True)
+        u2 = self._new(dev, B, 4 * H, 4 * W, n)
+        self._conv("upconv2", [u1], u2, act=ACT_PRELU, slope_t=a_t, ps=True)
+        out = self._new(dev, B, Cimg, 4 * H, 4 * W)               # NCHW boundary tensor
+        out_v = out.permute(0, 2, 3, 1)
+        centre = x[:, T // 2].permute(0, 2, 3, 1)                 # (B,H,W,Cimg) view of the centre LR frame
+        cv, ov = view(centre), view(out_v)
+        check(L.fcvsr_bilinear_up4(C.byref(cv), B, H, W, C.byref(ov), st), "fcvsr_bilinear_up4")
+        self._conv("conv_last0", [u2], out_v, res=[out_v])
+        if self.taps is not None:
+            self.taps["out"] = out.clone()
+        return out

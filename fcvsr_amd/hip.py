@@ -33,6 +33,13 @@ class ConvDesc(C.Structure):
                 ("res", View * 2), ("res_scale", C.c_float * 2), ("dst", View), ("pixel_shuffle", C.c_int32)]
 
 
+# bench.py instrumentation: when PROFILE is a list, every conv launch is bracketed by HIP events on the launch stream and
+# (start, stop, algorithmic_flops) is appended.  None (default) = no instrumentation.
+PROFILE = None
+COMPUTE_DTYPE = "f32"
+DOMINANT_KERNEL = "conv_direct_kernel"
+
+
 class HipError(RuntimeError):
     pass
 
@@ -141,5 +148,14 @@ def conv2d(srcs: Sequence[torch.Tensor], wpacked: torch.Tensor, ksize: int, cout
         d.res_scale[i] = res_scale[i] if i < len(res_scale) else 1.0
     d.dst = view(dst)
     d.pixel_shuffle = int(pixel_shuffle)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().fcvsr_conv2d(C.byref(d), stream_ptr()), "fcvsr_conv2d")
+        e1.record()
+        ho = (d.H + 2 * d.pad - d.kh) // stride + 1
+        wo = (d.W + 2 * d.pad - d.kw) // stride + 1
+        PROFILE.append((e0, e1, 2.0 * d.B * ho * wo * cout * cin * ksize * ksize))
+        return dst
     check(lib().fcvsr_conv2d(C.byref(d), stream_ptr()), "fcvsr_conv2d")
     return dst

@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--model", choices=["S", "full"], default="S")
     ap.add_argument("--height", type=int, default=180)
     ap.add_argument("--width", type=int, default=320)
+    ap.add_argument("--precision", choices=["f32", "bf16", "f16"], default="bf16",
+                    help="conv arithmetic: bf16/f16 MFMA operands with f32 accumulate (BASELINE config), or exact f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -84,6 +86,7 @@ def main():
     model = getattr(A, ctor)()
     model.load_state_dict(sd, strict=True)
     model = model.to(dev)
+    model.precision = args.precision
     B, H, W = args.batch, args.height, args.width
     rs = np.random.RandomState(1 + rank)                      # different clips per rank, same weights
     x = torch.from_numpy(rs.rand(B, 7, 1, H, W).astype(np.float32)).to(dev)
@@ -124,15 +127,19 @@ def main():
         torch.cuda.synchronize()
         recs = hip.PROFILE
         hip.PROFILE = None
-        tot_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
-        tot_fl = sum(f for _, _, f in recs)
-        dtype = hip.COMPUTE_DTYPE
-        peak = PEAK_TFLOPS[dtype]
+        kind = "direct" if args.precision == "f32" else "mfma"
+        dom = [r for r in recs if r[3] == kind]
+        tot_ms = sum(a.elapsed_time(b) for a, b, _, _ in dom)
+        tot_fl = sum(f for _, _, f, _ in dom)
+        all_fl = sum(f for _, _, f, _ in recs)
+        peak = PEAK_TFLOPS[args.precision]
         ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         roofline = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 5), "traffic": None, "kernel": hip.DOMINANT_KERNEL,
-                    "launches_per_step": len(recs), "avg_launch_us": round(tot_ms * 1e3 / max(1, len(recs)), 2),
-                    "flops_per_step": tot_fl}
+                    "frac": round(ach / peak, 5), "traffic": None,
+                    "kernel": "conv_direct_kernel" if kind == "direct" else "conv_mfma_kernel",
+                    "launches_per_step": len(dom), "avg_launch_us": round(tot_ms * 1e3 / max(1, len(dom)), 2),
+                    "flops_per_step_kernel": tot_fl, "flops_per_step_all_convs": all_fl,
+                    "kernel_ms_per_step": round(tot_ms, 3)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -157,7 +164,7 @@ def main():
             "metric": "SR frames/sec (7-frame window, 4x 180x320->720x1280)", "value": round(fps, 3),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": hip.COMPUTE_DTYPE, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"FCVSR-{args.model} 4x inference, {B}x7x{H}x{W} -> {4*H}x{4*W} synthetic clips, "
                                    f"random-init (key-seeded) weights", "batch_per_gpu": B, "parallelism": f"clip-dp{world}"},
             "frames_per_sec_per_gpu": round(fps / world, 3),

@@ -13,6 +13,8 @@ There is no CPU / eager fallback - a CPU tensor or a missing library raises.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.init as init
@@ -184,6 +186,9 @@ class _GShiftBase(nn.Module):
         self.MFFRblock = MultiFreq_Refinment(dim=n, Freq_Inv=Freq_Inv, mode="gaussian")
         self.upconv_fuse = nn.Conv2d(n + n // 4 + n // 16, n, 3, 1, 1, bias=True)
         self._engine = None
+        # arithmetic of the conv layers: "f32" = exact f32 (parity mode, default); "bf16" / "f16" = matrix cores with
+        # 16-bit operands and f32 accumulation (activations stay f32 in HBM).  Not part of state_dict.
+        self.precision = os.environ.get("FCVSR_PRECISION", "f32")
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: float (B, 7, C, H, W) in [0,1] on a HIP device -> (B, C, 4H, 4W)."""

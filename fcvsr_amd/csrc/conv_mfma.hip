@@ -1,0 +1,454 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_32x32x16_{bf16,f16}), im2col-free.
+//
+//   GEMM view:  D[pixel][cout] = sum_{tap, cin} A[pixel + tap][cin] * W[tap][cout][cin]      (f32 accumulate)
+//
+// Workgroup = 256 threads (4 waves) -> output tile of 8 rows x 32 pixels x NT output channels.
+//   * The (8+2p) x (32+2p) input halo tile of one 64-channel chunk is staged ONCE into LDS (converted f32 -> 16-bit while
+//     staging; activations stay f32 in HBM so the residual trunk never accumulates 16-bit rounding) and is re-read for all
+//     k*k taps: the 9 shifted A operands of a 3x3 conv are just 9 different LDS base addresses (no im2col buffer).
+//   * A wave owns 2 tile rows (= 2 MFMA M-fragments of 32 pixels) x NT couts (NT/32 N-fragments): (2 + NT/32) ds_read_b128
+//     feed 2*NT/32 MFMAs per 16-deep k-step.
+//   * LDS rows are padded by 16 bytes (72 halfwords per 64-channel pixel) which makes every ds_read_b128 of a fragment
+//     (32 consecutive pixels / couts, same k) conflict-free: bank step = 36 dwords -> 16 distinct 4-bank slots per lane group.
+//   * Weights ([tap][cout][cin], 16-bit, cin contiguous) stream tap by tap: global -> registers (prefetched under the MFMAs
+//     of the previous tap) -> LDS.  LDS footprint 67 KiB (NT<=128) -> 2 workgroups per CU overlap each other's stalls.
+//   * Epilogue straight from the accumulators: bias, ReLU/LeakyReLU/PReLU, up to two scaled residual inputs, optional
+//     PixelShuffle(2) scatter; a half-wave stores 32 consecutive couts of one pixel = one 128-byte line.
+//   * 1x1 convolutions run in "flat" mode: the B*H*W pixels are tiled as a 1-D list, so odd widths (Wf = W/2+1) cost nothing.
+//   * Up to 3 "groups" (e.g. the three pyramid levels of BlockRCB, which share weights) run in ONE launch so that the small
+//     levels do not leave most of the 256 CUs idle.
+// Replaces nn.Conv2d(+bias+activation+residual+cat+PixelShuffle) for every stride-1 layer of the path (see fcvsr_hip.h).
+#include <stdlib.h>
+#include "common.h"
+
+namespace fcvsr {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int kTH = 8, kTW = 32, kCK = 64, kLD = kCK + 8;  // tile rows/cols, channel chunk, padded LDS row (halfwords)
+
+struct MGroup {
+  View src[3];
+  View res[2];
+  View dst;
+  int B, H, W;         // spatial size (stride-1 "same" conv: output size == input size)
+  int tiles_x, tiles_y;
+  int tile_begin;      // first flattened tile id of this group
+};
+
+struct MfmaArgs {
+  int n_groups;
+  MGroup g[3];
+  int n_src, n_res;
+  int seg_c[3];        // channels per source segment
+  int cin_total, cin16, cin_pad, cout, cout_pad, n_nblk;
+  const uint16_t* w;   // [taps][cout_pad][cin_pad]
+  const float* bias;
+  int act;
+  float slope;
+  const float* slope_ptr;
+  float rs[2];
+  int ps;
+  int flat;            // 1x1: treat pixels as a flat list of B*H*W
+  int dbg;             // ablation switches for profiling builds (FCVSR_MFMA_DBG): 1 skip staging, 2 skip MFMA, 4 skip stores
+};
+
+template <bool BF16>
+__device__ __forceinline__ uint2 cvt4(float4 v) {
+  if (BF16) {
+    bf16x4_t c = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    return __builtin_bit_cast(uint2, c);
+  } else {
+    f16x4_t c = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    return __builtin_bit_cast(uint2, c);
+  }
+}
+
+template <bool BF16>
+__device__ __forceinline__ f32x16_t mfma(uint4 a, uint4 b, f32x16_t c) {
+  if (BF16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+struct EpiCtx {
+  int act, n_res, ps, flat, H, W, b;
+  float slope, rs0, rs1;
+  long long npix;
+  View res0, res1, dst;
+};
+
+// Epilogue for one pixel x 4 consecutive output channels (n..n+3) held as a float4 (after the LDS transpose).
+// Element offsets are 32-bit (host checks every tensor spans < 2^31 elements).
+__device__ __forceinline__ void epilogue_quad(const EpiCtx& e, float4 v, const float* bias, int cout, int n, int py, int px,
+                                              long long pflat) {
+  const bool pok = e.flat ? (pflat < e.npix) : ((py < e.H) && (px < e.W));
+  if (!pok || n >= cout) return;
+  const bool full = (n + 3 < cout);
+  float x[4] = {v.x, v.y, v.z, v.w};
+  if (bias) {
+    if (full) {
+      const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+      x[0] += b4.x; x[1] += b4.y; x[2] += b4.z; x[3] += b4.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (n + q < cout) x[q] += bias[n + q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (e.act == FCVSR_ACT_RELU) x[q] = fmaxf(x[q], 0.f);
+    else if (e.act == FCVSR_ACT_LEAKY || e.act == FCVSR_ACT_PRELU) x[q] = x[q] >= 0.f ? x[q] : x[q] * e.slope;
+  }
+  if (e.n_res > 0) {
+    const View& rv = e.res0;
+    const int o = (e.flat ? (int)pflat * (int)rv.sx : (e.b * (int)rv.sb + py * (int)rv.sy + px * (int)rv.sx));
+    if (full && rv.sc == 1) {
+      const float4 r4 = *reinterpret_cast<const float4*>(rv.p + o + n);
+      x[0] = fmaf(e.rs0, r4.x, x[0]); x[1] = fmaf(e.rs0, r4.y, x[1]); x[2] = fmaf(e.rs0, r4.z, x[2]); x[3] = fmaf(e.rs0, r4.w, x[3]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (n + q < cout) x[q] = fmaf(e.rs0, rv.p[o + (n + q) * (int)rv.sc], x[q]);
+    }
+  }
+  if (e.n_res > 1) {
+    const View& rv = e.res1;
+    const int o = (e.flat ? (int)pflat * (int)rv.sx : (e.b * (int)rv.sb + py * (int)rv.sy + px * (int)rv.sx));
+    if (full && rv.sc == 1) {
+      const float4 r4 = *reinterpret_cast<const float4*>(rv.p + o + n);
+      x[0] = fmaf(e.rs1, r4.x, x[0]); x[1] = fmaf(e.rs1, r4.y, x[1]); x[2] = fmaf(e.rs1, r4.z, x[2]); x[3] = fmaf(e.rs1, r4.w, x[3]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (n + q < cout) x[q] = fmaf(e.rs1, rv.p[o + (n + q) * (int)rv.sc], x[q]);
+    }
+  }
+  const View& d = e.dst;
+  if (e.ps) {
+    // n..n+3 = the 2x2 sub-pixels (i,j) of output channel n/4 (cout % 4 == 0 is checked on the host)
+    int qy = py, qx = px, qb = e.b;
+    if (e.flat) {
+      qx = (int)(pflat % e.W);
+      qy = (int)((pflat / e.W) % e.H);
+      qb = (int)(pflat / ((long long)e.W * e.H));
+    }
+    float* dp = d.p + qb * (int)d.sb + (2 * qy) * (int)d.sy + (2 * qx) * (int)d.sx + (n >> 2) * (int)d.sc;
+    dp[0] = x[0];
+    dp[(int)d.sx] = x[1];
+    dp[(int)d.sy] = x[2];
+    dp[(int)d.sy + (int)d.sx] = x[3];
+  } else {
+    const int o = (e.flat ? (int)pflat * (int)d.sx : (e.b * (int)d.sb + py * (int)d.sy + px * (int)d.sx));
+    if (full && d.sc == 1) {
+      *reinterpret_cast<float4*>(d.p + o + n) = make_float4(x[0], x[1], x[2], x[3]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (n + q < cout) d.p[o + (n + q) * (int)d.sc] = x[q];
+    }
+  }
+}
+
+template <bool BF16, int NT, int KS>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(MfmaArgs a) {
+  constexpr int PAD = KS / 2;
+  constexpr int HH = kTH + 2 * PAD, HWD = kTW + 2 * PAD;
+  constexpr int NF = NT / 32;
+  constexpr int WLOADS = NT * kCK * 2 / 16 / 256;   // 16-byte weight loads per thread per tap (NT/32)
+  extern __shared__ __align__(16) uint16_t lds[];
+  uint16_t* A_s = lds;                               // [HH*HWD][kLD]
+  uint16_t* B_s = lds + HH * HWD * kLD;              // [NT][kLD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  // ---- which tile ----------------------------------------------------------------------------------------------------
+  const int nb = blockIdx.x % a.n_nblk;
+  const int tflat = blockIdx.x / a.n_nblk;
+  int gi = 0;
+  if (a.n_groups > 1 && tflat >= a.g[1].tile_begin) gi = 1;
+  if (a.n_groups > 2 && tflat >= a.g[2].tile_begin) gi = 2;
+  const MGroup& G = a.g[gi];
+  const int tl = tflat - G.tile_begin;
+  const int n0 = nb * NT;
+  int b, ty0, tx0;
+  long long flat0 = 0;
+  const long long npix = (long long)G.B * G.H * G.W;
+  if (a.flat) {
+    flat0 = (long long)tl * (kTH * kTW);
+    b = 0; ty0 = 0; tx0 = 0;
+  } else {
+    const int per_img = G.tiles_x * G.tiles_y;
+    b = tl / per_img;
+    const int t2 = tl % per_img;
+    ty0 = (t2 / G.tiles_x) * kTH;
+    tx0 = (t2 % G.tiles_x) * kTW;
+  }
+
+  f32x16_t acc[2][NF];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][nf][i] = 0.f;
+
+  for (int c0 = 0; c0 < a.cin16; c0 += kCK) {
+    const int ck = (a.cin16 - c0) < kCK ? (a.cin16 - c0) : kCK;       // multiple of 16
+    __syncthreads();   // every wave is done reading A_s / B_s of the previous chunk
+    // ---- stage the halo tile of channels [c0, c0+64): f32 HBM -> 16-bit LDS -------------------------------------------
+    {
+      constexpr int NHP = HH * HWD;                    // halo pixels
+      constexpr int ITERS = (NHP * 16 + 255) / 256;    // 16 channel-quads per pixel, 256 threads
+      const int q = tid & 15;
+      const int c = c0 + q * 4;
+      const bool cok = (c < a.cin_total) && !(a.dbg & 1);
+      int s_ = 0, cl = c;
+      if (cl >= a.seg_c[0]) { cl -= a.seg_c[0]; s_ = 1; if (cl >= a.seg_c[1]) { cl -= a.seg_c[1]; s_ = 2; } }
+      const View sv = G.src[cok ? s_ : 0];
+      const float* sbase = sv.p + (a.flat ? 0ll : (long long)b * sv.sb) + cl;
+      constexpr int UNR = 8;
+#pragma unroll 1
+      for (int it0 = 0; it0 < ITERS; it0 += UNR) {
+        float4 v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int hp = (tid >> 4) + (it0 + u) * 16;
+          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (cok && hp < NHP) {
+            if (a.flat) {
+              const long long p = flat0 + hp;
+              if (p < npix) v[u] = *reinterpret_cast<const float4*>(sbase + p * sv.sx);
+            } else {
+              const int hy = hp / HWD, hx = hp - hy * HWD;     // HWD is a compile-time constant (mul-shift)
+              const int iy = ty0 + hy - PAD, ix = tx0 + hx - PAD;
+              if (iy >= 0 && iy < G.H && ix >= 0 && ix < G.W)
+                v[u] = *reinterpret_cast<const float4*>(sbase + (long long)iy * sv.sy + (long long)ix * sv.sx);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int hp = (tid >> 4) + (it0 + u) * 16;
+          if (hp < NHP) *reinterpret_cast<uint2*>(A_s + hp * kLD + q * 4) = cvt4<BF16>(v[u]);
+        }
+      }
+    }
+    // ---- taps: weights global -> regs -> LDS, then MFMA ---------------------------------------------------------------
+    uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;   // named (not an array): must stay in VGPRs
+    // weights for chunk columns beyond ck are never read by the MFMA loop (kk*16 < ck), but the 16-byte loads must stay
+    // inside the packed buffer: the packer pads cin_pad to a multiple of 64.
+    const uint16_t* wbase = a.w + ((long long)n0 + (tid >> 3)) * a.cin_pad + c0 + (tid & 7) * 8;
+    const long long wtap = (long long)a.cout_pad * a.cin_pad;   // halfwords per tap
+    const long long wrow32 = 32ll * a.cin_pad;                   // i*256 threads = 32 more cout rows
+#define FCVSR_FETCH_W(TAP)                                                                             \
+  do {                                                                                                 \
+    const uint16_t* wp_ = wbase + (TAP) * wtap;                                                        \
+    w0 = *reinterpret_cast<const uint4*>(wp_);                                                         \
+    if (WLOADS > 1) w1 = *reinterpret_cast<const uint4*>(wp_ + wrow32);                                \
+    if (WLOADS > 2) w2 = *reinterpret_cast<const uint4*>(wp_ + 2 * wrow32);                            \
+    if (WLOADS > 3) w3 = *reinterpret_cast<const uint4*>(wp_ + 3 * wrow32);                            \
+  } while (0)
+    FCVSR_FETCH_W(0);
+#pragma unroll 1
+    for (int tap = 0; tap < KS * KS; ++tap) {
+      if (tap > 0) __syncthreads();      // B_s of the previous tap fully consumed
+      {
+        uint16_t* bp = B_s + (tid >> 3) * kLD + (tid & 7) * 8;
+        *reinterpret_cast<uint4*>(bp) = w0;
+        if (WLOADS > 1) *reinterpret_cast<uint4*>(bp + 32 * kLD) = w1;
+        if (WLOADS > 2) *reinterpret_cast<uint4*>(bp + 64 * kLD) = w2;
+        if (WLOADS > 3) *reinterpret_cast<uint4*>(bp + 96 * kLD) = w3;
+      }
+      __syncthreads();                   // A_s (first tap) and B_s visible
+      if (tap + 1 < KS * KS) FCVSR_FETCH_W(tap + 1);
+      const int ky = tap / KS, kx = tap - ky * KS;
+      const uint16_t* arow0 = A_s + ((2 * wave + ky) * HWD + r + kx) * kLD + h * 8;
+      const uint16_t* brow = B_s + r * kLD + h * 8;
+#pragma unroll
+      for (int kk = 0; kk < kCK / 16; ++kk) {
+        if (kk * 16 < ck && !(a.dbg & 2)) {
+          uint4 af[2], bf[NF];
+          af[0] = *reinterpret_cast<const uint4*>(arow0 + kk * 16);
+          af[1] = *reinterpret_cast<const uint4*>(arow0 + HWD * kLD + kk * 16);
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) bf[nf] = *reinterpret_cast<const uint4*>(brow + nf * 32 * kLD + kk * 16);
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[m][nf] = mfma<BF16>(af[m], bf[nf], acc[m][nf]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: accumulators -> per-wave LDS transpose -> 16-byte (4-channel) epilogue + stores ------------------------
+  // A lane holds one cout column x 16 pixels; storing that directly is one dword per lane per instruction (store-issue
+  // bound, ~1 TB/s).  Through LDS each lane gets 4 consecutive couts of one pixel: bias / residual loads and the output
+  // store are 16 bytes per lane and a wave instruction covers whole 256-byte runs of a pixel's channels.
+  float slope = a.slope;
+  if (a.act == FCVSR_ACT_PRELU) slope = a.slope_ptr[0];
+  EpiCtx e;
+  e.act = a.act; e.slope = slope; e.n_res = a.n_res; e.rs0 = a.rs[0]; e.rs1 = a.rs[1]; e.ps = a.ps; e.flat = a.flat;
+  e.res0 = G.res[0]; e.res1 = G.res[1]; e.dst = G.dst; e.H = G.H; e.W = G.W; e.b = b; e.npix = npix;
+  constexpr int EW = NT >= 64 ? 64 : 32;        // couts per pass
+  constexpr int EROW = EW + 4;                  // padded row (floats): conflict-free b32 writes and b128 reads
+  constexpr int QPR = EW / 4;                   // float4 per pixel row
+  __syncthreads();                              // every wave is done with A_s / B_s
+  float* E_s = reinterpret_cast<float*>(lds) + wave * (32 * EROW);
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int yo = 2 * wave + m;
+#pragma unroll
+    for (int nh = 0; nh < NT / EW; ++nh) {
+#pragma unroll
+      for (int nf2 = 0; nf2 < EW / 32; ++nf2) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          E_s[((i & 3) + 8 * (i >> 2) + 4 * h) * EROW + nf2 * 32 + r] = acc[m][nh * (EW / 32) + nf2][i];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 32 * QPR / 64; ++j) {
+        const int idx = j * 64 + lane;
+        const int cq = idx % QPR, p = idx / QPR;
+        const float4 v = *reinterpret_cast<const float4*>(E_s + p * EROW + cq * 4);
+        if (!(a.dbg & 4) || v.x == 12345.678f)
+          epilogue_quad(e, v, a.bias, a.cout, n0 + nh * EW + cq * 4, ty0 + yo, tx0 + p, flat0 + yo * kTW + p);
+        asm volatile("" ::: "memory");
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+template <bool BF16, int NT, int KS>
+static hipError_t launch_mfma(const MfmaArgs& a, int total_tiles, hipStream_t st) {
+  constexpr int PAD = KS / 2;
+  const size_t lds = ((size_t)(kTH + 2 * PAD) * (kTW + 2 * PAD) * kLD + (size_t)NT * kLD) * sizeof(uint16_t);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_mfma_kernel<BF16, NT, KS>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_mfma_kernel<BF16, NT, KS>), dim3(total_tiles * a.n_nblk), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+template <bool BF16>
+static hipError_t dispatch(const MfmaArgs& a, int nt, int ks, int total_tiles, hipStream_t st) {
+  if (ks == 3) {
+    if (nt == 128) return launch_mfma<BF16, 128, 3>(a, total_tiles, st);
+    if (nt == 64) return launch_mfma<BF16, 64, 3>(a, total_tiles, st);
+    return launch_mfma<BF16, 32, 3>(a, total_tiles, st);
+  }
+  if (nt == 128) return launch_mfma<BF16, 128, 1>(a, total_tiles, st);
+  if (nt == 64) return launch_mfma<BF16, 64, 1>(a, total_tiles, st);
+  return launch_mfma<BF16, 32, 1>(a, total_tiles, st);
+}
+
+}  // namespace fcvsr
+
+using namespace fcvsr;
+
+// channel-contiguous res/dst views are accessed 16 bytes at a time
+static bool vec_view_ok(const fcvsr_view& v) {
+  return v.sc != 1 || v.c < 4 || (v.sx % 4 == 0 && v.sy % 4 == 0 && v.sb % 4 == 0 && ((uintptr_t)v.ptr % 16) == 0);
+}
+
+static bool src_ok(const fcvsr_view& v) {
+  return v.ptr && v.dtype == FCVSR_F32 && v.sc == 1 && v.c % 4 == 0 && v.sx % 4 == 0 && v.sy % 4 == 0 && v.sb % 4 == 0 &&
+         ((uintptr_t)v.ptr % 16) == 0;
+}
+
+extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int mma_dtype, void* stream) {
+  FCVSR_CHECK_ARG(descs != nullptr && n_groups >= 1 && n_groups <= 3, "1..3 problem groups");
+  FCVSR_CHECK_ARG(mma_dtype == FCVSR_BF16 || mma_dtype == FCVSR_F16, "mma_dtype must be BF16 or F16");
+  const fcvsr_conv_desc& d0 = descs[0];
+  FCVSR_CHECK_ARG(d0.kh == d0.kw && (d0.kh == 1 || d0.kh == 3) && d0.stride == 1 && d0.pad == d0.kh / 2,
+                  "MFMA path: 1x1 or 3x3, stride 1, same padding");
+  FCVSR_CHECK_ARG(d0.n_src >= 1 && d0.n_src <= 3 && d0.n_res >= 0 && d0.n_res <= 2 && d0.cout > 0, "bad descriptor");
+  FCVSR_CHECK_ARG(d0.weight != nullptr && d0.cout_pad % 128 == 0 && d0.cout_pad >= d0.cout, "weight must be MFMA-packed");
+  FCVSR_CHECK_ARG(!(d0.act == FCVSR_ACT_PRELU) || d0.slope_ptr != nullptr, "PReLU needs slope_ptr");
+  FCVSR_CHECK_ARG(!d0.pixel_shuffle || d0.cout % 4 == 0, "pixel_shuffle needs cout%4==0");
+  MfmaArgs a;
+  a.n_groups = n_groups;
+  a.n_src = d0.n_src;
+  a.n_res = d0.n_res;
+  int cin = 0;
+  for (int s = 0; s < 3; ++s) {
+    a.seg_c[s] = s < d0.n_src ? d0.src[s].c : (1 << 30);
+    if (s < d0.n_src) cin += d0.src[s].c;
+  }
+  a.cin_total = cin;
+  a.cin16 = (cin + 15) / 16 * 16;
+  a.cin_pad = (cin + 63) / 64 * 64;   // packer pads cin to a multiple of 64 (16-byte weight loads stay in bounds)
+  a.cout = d0.cout;
+  a.cout_pad = d0.cout_pad;
+  const int nt = d0.cout > 64 ? 128 : (d0.cout > 32 ? 64 : 32);
+  a.n_nblk = (d0.cout + nt - 1) / nt;
+  a.w = (const uint16_t*)d0.weight;
+  a.bias = d0.bias;
+  a.act = d0.act;
+  a.slope = d0.slope;
+  a.slope_ptr = d0.slope_ptr;
+  a.rs[0] = d0.res_scale[0];
+  a.rs[1] = d0.res_scale[1];
+  a.ps = d0.pixel_shuffle;
+  a.flat = d0.kh == 1 ? 1 : 0;
+  {
+    const char* dbg = getenv("FCVSR_MFMA_DBG");
+    a.dbg = dbg ? atoi(dbg) : 0;
+  }
+  int tiles = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    const fcvsr_conv_desc& d = descs[g];
+    FCVSR_CHECK_ARG(d.kh == d0.kh && d.kw == d0.kw && d.stride == 1 && d.n_src == d0.n_src && d.n_res == d0.n_res &&
+                        d.cout == d0.cout && d.weight == d0.weight && d.bias == d0.bias && d.act == d0.act &&
+                        d.pixel_shuffle == d0.pixel_shuffle,
+                    "groups must share weights and epilogue");
+    FCVSR_CHECK_ARG(d.B > 0 && d.H > 0 && d.W > 0, "empty problem");
+    MGroup& G = a.g[g];
+    for (int s = 0; s < d.n_src; ++s) {
+      FCVSR_CHECK_ARG(src_ok(d.src[s]) && d.src[s].c == d0.src[s].c, "src: f32, channel-contiguous, 16-byte aligned, c%4==0");
+      G.src[s] = to_view(d.src[s]);
+      if (a.flat)
+        FCVSR_CHECK_ARG(d.src[s].sy == d.src[s].sx * d.W && d.src[s].sb == d.src[s].sy * d.H, "1x1 needs uniformly strided pixels");
+    }
+    for (int q = 0; q < d.n_res; ++q) {
+      FCVSR_CHECK_ARG(d.res[q].ptr && d.res[q].dtype == FCVSR_F32 && vec_view_ok(d.res[q]), "res must be f32, 16-byte aligned");
+      G.res[q] = to_view(d.res[q]);
+      if (a.flat)
+        FCVSR_CHECK_ARG(d.res[q].sy == d.res[q].sx * d.W && d.res[q].sb == d.res[q].sy * d.H, "1x1 needs uniformly strided res");
+    }
+    FCVSR_CHECK_ARG(d.dst.ptr && d.dst.dtype == FCVSR_F32 && vec_view_ok(d.dst), "dst must be f32, 16-byte aligned");
+    FCVSR_CHECK_ARG(d.bias == nullptr || ((uintptr_t)d.bias % 16) == 0, "bias must be 16-byte aligned");
+    G.dst = to_view(d.dst);
+    if (a.flat && !d.pixel_shuffle)
+      FCVSR_CHECK_ARG(d.dst.sy == d.dst.sx * d.W && d.dst.sb == d.dst.sy * d.H, "1x1 needs uniformly strided dst");
+    G.B = d.B; G.H = d.H; G.W = d.W;
+    G.tile_begin = tiles;
+    if (a.flat) {
+      G.tiles_x = 1; G.tiles_y = 1;
+      tiles += cdiv((long long)d.B * d.H * d.W, kTH * kTW);
+    } else {
+      G.tiles_x = cdiv(d.W, kTW);
+      G.tiles_y = cdiv(d.H, kTH);
+      tiles += d.B * G.tiles_x * G.tiles_y;
+    }
+  }
+  for (int g = n_groups; g < 3; ++g) a.g[g] = a.g[0];
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = (mma_dtype == FCVSR_BF16) ? dispatch<true>(a, nt, d0.kh, tiles, st) : dispatch<false>(a, nt, d0.kh, tiles, st);
+  if (e != hipSuccess) {
+    set_error("fcvsr_conv2d_mfma: launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}

@@ -20,12 +20,14 @@ struct FftPlan {
   int N;
   int nfac;
   int fac[20];
+  unsigned magic[20];   // ceil(2^32 / Ns) of each stage (Ns = product of the previous radices): j / Ns == umulhi(j, magic)
 };
 
 static bool make_plan(int N, FftPlan* p) {
   p->N = N;
   p->nfac = 0;
   int n = N;
+  // power-of-two radices first (their Ns stay powers of two), then 3, 5, then any other prime (generic butterfly)
   while (n % 4 == 0) { p->fac[p->nfac++] = 4; n /= 4; }
   while (n % 2 == 0) { p->fac[p->nfac++] = 2; n /= 2; }
   for (int f = 3; f <= n; f += 2) {
@@ -36,7 +38,13 @@ static bool make_plan(int N, FftPlan* p) {
     }
   }
   if (N == 1) { p->fac[0] = 1; p->nfac = 1; }
-  return n == 1;
+  if (n != 1 || N >= 65536) return false;
+  unsigned long long Ns = 1;
+  for (int s = 0; s < p->nfac; ++s) {
+    p->magic[s] = Ns == 1 ? 0u : (unsigned)(((1ull << 32) + Ns - 1) / Ns);   // exact for j < 2^16
+    Ns *= p->fac[s];
+  }
+  return true;
 }
 
 // LDS layout (floats): re0[N*L] im0[N*L] re1[N*L] im1[N*L] tw[2*N]
@@ -49,47 +57,123 @@ __device__ __forceinline__ void make_twiddles(float* tw, int N, bool inverse) {
   }
 }
 
-// runs all stages; returns 0 if the result is in buffer 0, 1 if in buffer 1
+struct Cx { float r, i; };
+__device__ __forceinline__ Cx cadd(Cx a, Cx b) { return {a.r + b.r, a.i + b.i}; }
+__device__ __forceinline__ Cx csub(Cx a, Cx b) { return {a.r - b.r, a.i - b.i}; }
+__device__ __forceinline__ Cx cmul(Cx a, Cx w) { return {fmaf(a.r, w.r, -a.i * w.i), fmaf(a.r, w.i, a.i * w.r)}; }
+// multiply by -i (forward) or +i (inverse)
+template <bool INV> __device__ __forceinline__ Cx rot90(Cx a) { return INV ? Cx{-a.i, a.r} : Cx{a.i, -a.r}; }
+
+// One Stockham stage with a register butterfly of compile-time radix R: thread = (butterfly j, channel lane l).
+// y[(jhi*Ns*R + k + p*Ns)] = sum_q x[j + q*M] * W_N^(q*k*mult) * W_R^(p*q),  k = j % Ns, jhi = j / Ns, M = N/R.
+template <int R, bool INV>
+__device__ __forceinline__ void stage_radix(const float* xr, const float* xi, float* yr, float* yi, const float* tw, int N,
+                                            int Ns, unsigned magic, int L, int logL) {
+  const int M = N / R;
+  const int mult = M / Ns;                       // N / (Ns*R)
+  for (int t = threadIdx.x; t < M * L; t += blockDim.x) {
+    const int l = t & (L - 1);
+    const int j = t >> logL;
+    const int jhi = Ns == 1 ? j : (int)__umulhi((unsigned)j, magic);
+    const int k = j - jhi * Ns;
+    Cx v[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int idx = (j + q * M) * L + l;
+      v[q] = {xr[idx], xi[idx]};
+      if (q > 0) {
+        const int e = q * k * mult;                // < N
+        v[q] = cmul(v[q], Cx{tw[2 * e], tw[2 * e + 1]});
+      }
+    }
+    Cx u[R];
+    if (R == 2) {
+      u[0] = cadd(v[0], v[1]); u[1] = csub(v[0], v[1]);
+    } else if (R == 4) {
+      const Cx a = cadd(v[0], v[2]), b = csub(v[0], v[2]), c = cadd(v[1], v[3]), d = rot90<INV>(csub(v[1], v[3]));
+      u[0] = cadd(a, c); u[2] = csub(a, c); u[1] = cadd(b, d); u[3] = csub(b, d);
+    } else if (R == 3) {
+      const Cx t1 = cadd(v[1], v[2]);
+      const Cx m = {v[0].r - 0.5f * t1.r, v[0].i - 0.5f * t1.i};
+      const Cx d0 = csub(v[1], v[2]);
+      const Cx sd = rot90<INV>(Cx{0.86602540378443865f * d0.r, 0.86602540378443865f * d0.i});
+      u[0] = cadd(v[0], t1); u[1] = cadd(m, sd); u[2] = csub(m, sd);
+    } else if (R == 5) {
+      const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;
+      const float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
+      const Cx t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+      u[0] = {v[0].r + t1.r + t2.r, v[0].i + t1.i + t2.i};
+      const Cx m1 = {v[0].r + c1 * t1.r + c2 * t2.r, v[0].i + c1 * t1.i + c2 * t2.i};
+      const Cx m2 = {v[0].r + c2 * t1.r + c1 * t2.r, v[0].i + c2 * t1.i + c1 * t2.i};
+      const Cx r1 = rot90<INV>(Cx{s1 * t3.r + s2 * t4.r, s1 * t3.i + s2 * t4.i});
+      const Cx r2 = rot90<INV>(Cx{s2 * t3.r - s1 * t4.r, s2 * t3.i - s1 * t4.i});
+      u[1] = cadd(m1, r1); u[4] = csub(m1, r1); u[2] = cadd(m2, r2); u[3] = csub(m2, r2);
+    }
+    const int o0 = (jhi * Ns * R + k) * L + l;
+#pragma unroll
+    for (int pq = 0; pq < R; ++pq) {
+      yr[o0 + pq * Ns * L] = u[pq].r;
+      yi[o0 + pq * Ns * L] = u[pq].i;
+    }
+  }
+}
+
+// Any other (prime) radix: one thread per OUTPUT element, r MACs each, inputs re-read from LDS (no register arrays).
+__device__ __forceinline__ void stage_generic(const float* xr, const float* xi, float* yr, float* yi, const float* tw, int N,
+                                              int Ns, int r, int L, int logL) {
+  const int M = N / r;
+  const int span = Ns * r;
+  const int mult = N / span;
+  for (int t = threadIdx.x; t < N * L; t += blockDim.x) {
+    const int l = t & (L - 1);
+    const int o = t >> logL;
+    const int k = o % Ns;
+    const int pq = (o / Ns) % r;
+    const int jhi = o / span;
+    const int j = jhi * Ns + k;
+    const int step = k + pq * Ns;
+    int e = 0;
+    float ar = 0.f, ai = 0.f;
+    for (int q = 0; q < r; ++q) {
+      const int idx = (j + q * M) * L + l;
+      const float vr = xr[idx], vi = xi[idx];
+      const float wr = tw[2 * e * mult], wi = tw[2 * e * mult + 1];
+      ar = fmaf(vr, wr, ar); ar = fmaf(-vi, wi, ar);
+      ai = fmaf(vr, wi, ai); ai = fmaf(vi, wr, ai);
+      e += step;
+      if (e >= span) e -= span;
+    }
+    yr[o * L + l] = ar;
+    yi[o * L + l] = ai;
+  }
+}
+
+// runs all stages; returns 0 if the result is in buffer 0, 1 if in buffer 1.  L must be a power of two.
+template <bool INV>
 __device__ __forceinline__ int run_stages(float* lds, const FftPlan& plan, int L) {
   const int N = plan.N;
   const int NL = N * L;
+  const int logL = 31 - __clz(L);
   const float* tw = lds + 4 * NL;
   int cur = 0;
   int Ns = 1;
   for (int s = 0; s < plan.nfac; ++s) {
     const int r = plan.fac[s];
-    const int M = N / r;
-    const int span = Ns * r;
-    const int mult = N / span;
     const float* xr = lds + cur * 2 * NL;
     const float* xi = xr + NL;
     float* yr = lds + (cur ^ 1) * 2 * NL;
     float* yi = yr + NL;
-    for (int t = threadIdx.x; t < NL; t += blockDim.x) {
-      const int l = t % L;
-      const int o = t / L;
-      const int k = o % Ns;
-      const int p = (o / Ns) % r;
-      const int jhi = o / span;
-      const int j = jhi * Ns + k;
-      const int step = k + p * Ns;
-      int e = 0;
-      float ar = 0.f, ai = 0.f;
-      for (int q = 0; q < r; ++q) {
-        const int idx = (j + q * M) * L + l;
-        const float vr = xr[idx], vi = xi[idx];
-        const float wr = tw[2 * e * mult], wi = tw[2 * e * mult + 1];
-        ar = fmaf(vr, wr, ar); ar = fmaf(-vi, wi, ar);
-        ai = fmaf(vr, wi, ai); ai = fmaf(vi, wr, ai);
-        e += step;
-        if (e >= span) e -= span;
-      }
-      yr[o * L + l] = ar;
-      yi[o * L + l] = ai;
+    const unsigned mg = plan.magic[s];
+    if (r == 4) stage_radix<4, INV>(xr, xi, yr, yi, tw, N, Ns, mg, L, logL);
+    else if (r == 2) stage_radix<2, INV>(xr, xi, yr, yi, tw, N, Ns, mg, L, logL);
+    else if (r == 3) stage_radix<3, INV>(xr, xi, yr, yi, tw, N, Ns, mg, L, logL);
+    else if (r == 5) stage_radix<5, INV>(xr, xi, yr, yi, tw, N, Ns, mg, L, logL);
+    else if (r > 1) stage_generic(xr, xi, yr, yi, tw, N, Ns, r, L, logL);
+    if (r > 1) {
+      __syncthreads();
+      cur ^= 1;
     }
-    __syncthreads();
-    cur ^= 1;
-    Ns = span;
+    Ns *= r;
   }
   return cur;
 }
@@ -105,19 +189,19 @@ __global__ __launch_bounds__(512) void rfft_rows_kernel(View src, int n, int H, 
   make_twiddles(lds + 4 * NL, W, false);
   const float* sp = src.p + (long long)b * src.sb + (long long)y * src.sy;
   for (int t = threadIdx.x; t < NL; t += blockDim.x) {
-    const int l = t % L, x = t / L;
+    const int l = t & (L - 1), x = t >> (31 - __clz(L));
     const int ca = c0 + l, cb = c0 + L + l;
     const float* px = sp + (long long)x * src.sx;
     lds[t] = ca < n ? px[(long long)ca * src.sc] : 0.f;
     lds[NL + t] = cb < n ? px[(long long)cb * src.sc] : 0.f;
   }
   __syncthreads();
-  const int cur = run_stages(lds, plan, L);
+  const int cur = run_stages<false>(lds, plan, L);
   const float* zr = lds + (cur ? 2 * NL : 0);
   const float* zi = zr + NL;
   float* op = spec + ((long long)(b * H + y) * Wf) * ps;
   for (int t = threadIdx.x; t < Wf * L; t += blockDim.x) {
-    const int l = t % L, k = t / L;
+    const int l = t & (L - 1), k = t >> (31 - __clz(L));
     const int kn = (W - k) % W;
     const float kr = zr[k * L + l], ki = zi[k * L + l];
     const float nr = zr[kn * L + l], ni = zi[kn * L + l];
@@ -138,7 +222,7 @@ __global__ __launch_bounds__(512) void fft_cols_kernel(const float* in, float* o
   const int c0 = blockIdx.y * L;
   make_twiddles(lds + 4 * NL, H, inverse != 0);
   for (int t = threadIdx.x; t < NL; t += blockDim.x) {
-    const int l = t % L, y = t / L;
+    const int l = t & (L - 1), y = t >> (31 - __clz(L));
     const int c = c0 + l;
     const float* px = in + ((long long)(b * H + y) * Wf + kx) * ps;
     const float m = mask ? mask[y * Wf + kx] : 1.f;
@@ -146,11 +230,11 @@ __global__ __launch_bounds__(512) void fft_cols_kernel(const float* in, float* o
     lds[NL + t] = c < n ? px[im_off + c] * m : 0.f;
   }
   __syncthreads();
-  const int cur = run_stages(lds, plan, L);
+  const int cur = inverse ? run_stages<true>(lds, plan, L) : run_stages<false>(lds, plan, L);
   const float* zr = lds + (cur ? 2 * NL : 0);
   const float* zi = zr + NL;
   for (int t = threadIdx.x; t < NL; t += blockDim.x) {
-    const int l = t % L, y = t / L;
+    const int l = t & (L - 1), y = t >> (31 - __clz(L));
     const int c = c0 + l;
     if (c < n) {
       float* px = out + ((long long)(b * H + y) * Wf + kx) * ps;
@@ -171,7 +255,7 @@ __global__ __launch_bounds__(512) void irfft_rows_kernel(const float* spec, long
   make_twiddles(lds + 4 * NL, W, true);
   const float* ip = spec + ((long long)(b * H + y) * Wf) * ps;
   for (int t = threadIdx.x; t < NL; t += blockDim.x) {
-    const int l = t % L, k = t / L;
+    const int l = t & (L - 1), k = t >> (31 - __clz(L));
     const int kk = (k <= W / 2) ? k : W - k;
     const bool cj = k > W / 2;
     const bool real_only = (kk == 0) || ((W % 2 == 0) && kk == W / 2);
@@ -186,12 +270,12 @@ __global__ __launch_bounds__(512) void irfft_rows_kernel(const float* spec, long
     lds[NL + t] = ai + br;
   }
   __syncthreads();
-  const int cur = run_stages(lds, plan, L);
+  const int cur = run_stages<true>(lds, plan, L);
   const float* zr = lds + (cur ? 2 * NL : 0);
   const float* zi = zr + NL;
   float* op = dst.p + (long long)b * dst.sb + (long long)y * dst.sy;
   for (int t = threadIdx.x; t < NL; t += blockDim.x) {
-    const int l = t % L, x = t / L;
+    const int l = t & (L - 1), x = t >> (31 - __clz(L));
     const int ca = c0 + l, cb = c0 + L + l;
     float* px = op + (long long)x * dst.sx;
     if (ca < n) px[(long long)ca * dst.sc] = zr[t] * scale;

@@ -70,27 +70,48 @@ __global__ void gc_stage2_kernel(const float* part, int nblk, int C, const float
   float* ctx = sm;
   float* hid = sm + C;
   float* scale = sm + 2 * C;
-  __shared__ float gmax_s, denom_s;
+  __shared__ float red[256];
   const int b = blockIdx.x;
   const float* pb = part + (long long)b * nblk * (C + 2);
-  if (threadIdx.x == 0) {
-    float gm = -INFINITY;
-    for (int k = 0; k < nblk; ++k) gm = fmaxf(gm, pb[(long long)k * (C + 2) + C]);
-    float den = 0.f;
-    for (int k = 0; k < nblk; ++k) {
-      const float sc = expf(pb[(long long)k * (C + 2) + C] - gm);
-      den = fmaf(pb[(long long)k * (C + 2) + C + 1], sc, den);
-    }
-    gmax_s = gm;
-    denom_s = den;
+  // global max of the per-block maxima (tree reduction, fixed order)
+  float gm = -INFINITY;
+  for (int k = threadIdx.x; k < nblk; k += blockDim.x) gm = fmaxf(gm, pb[(long long)k * (C + 2) + C]);
+  red[threadIdx.x] = gm;
+  __syncthreads();
+  for (int st = blockDim.x / 2; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+    __syncthreads();
   }
+  const float gmax_s = red[0];
   __syncthreads();
-  for (int k = threadIdx.x; k < nblk; k += blockDim.x) scale[k] = expf(pb[(long long)k * (C + 2) + C] - gmax_s);
+  float den = 0.f;
+  for (int k = threadIdx.x; k < nblk; k += blockDim.x) {
+    const float sc = expf(pb[(long long)k * (C + 2) + C] - gmax_s);
+    scale[k] = sc;
+    den = fmaf(pb[(long long)k * (C + 2) + C + 1], sc, den);
+  }
+  red[threadIdx.x] = den;
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  for (int st = blockDim.x / 2; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  const float denom_s = red[0];
+  __syncthreads();
+  // ctx[c]: 256 threads = (256/C) partial sums per channel over the blocks, then a fixed-order combine
+  {
+    const int R = blockDim.x / C;
+    const int sub = threadIdx.x / C, c = threadIdx.x % C;
     float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s = fmaf(pb[(long long)k * (C + 2) + c], scale[k], s);
-    ctx[c] = s / denom_s;
+    if (sub < R)
+      for (int k = sub; k < nblk; k += R) s = fmaf(pb[(long long)k * (C + 2) + c], scale[k], s);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < C) {
+      float t = 0.f;
+      for (int q = 0; q < R; ++q) t += red[q * C + threadIdx.x];
+      ctx[threadIdx.x] = t / denom_s;
+    }
   }
   __syncthreads();
   for (int o = threadIdx.x; o < C; o += blockDim.x) {

@@ -64,6 +64,13 @@ class Engine:
         self._warned = False
         self.taps: Optional[dict] = None       # set to a dict to record NCHW copies of intermediate results (tests)
 
+    @property
+    def precision(self) -> str:
+        p = getattr(self._model(), "precision", "f32")
+        if p not in ("f32", "bf16", "f16"):
+            raise ValueError(f"precision must be 'f32', 'bf16' or 'f16', got {p!r}")
+        return p
+
     # ---------------------------------------------------------------------------------------------- weights
     def _refresh(self, dev):
         m = self._model()
@@ -71,26 +78,36 @@ class Engine:
         ver = tuple((k, v._version, v.data_ptr()) for k, v in sd.items()) + (str(dev),)
         if ver == self._versions:
             return
-        P: Dict[str, torch.Tensor] = {}
-        n, A = m.n_feats, m.ACNum
         for k, v in sd.items():
             if v.device != dev:
                 raise RuntimeError(f"parameter {k} is on {v.device}, input on {dev}: call model.to(device) first")
-            if k.endswith(".weight") and v.dim() == 4 and ".Conv." not in k:
-                if k == "MGAA.F.1.weight":
-                    rows = torch.cat([torch.arange(i * 6 * n, i * 6 * n + 3 * n) for i in range(A)]).to(dev)
-                    P[k] = hip.pack_conv_weight(v.detach()[rows])
-                    P["MGAA.F.1.bias"] = sd["MGAA.F.1.bias"].detach()[rows].contiguous()
-                elif k == "MGAA.convcorr.0.weight":
-                    w = v.detach()
-                    wp = torch.zeros(w.shape[0], 2 * n + 84, 1, 1, device=dev, dtype=torch.float32)
-                    wp[:, : 2 * n + 81] = w[:, : 2 * n + 81]      # drop the 2 zero-flow inputs, pad corr 81 -> 84
-                    P[k] = hip.pack_conv_weight(wp)
-                else:
-                    P[k] = hip.pack_conv_weight(v.detach())
-        self._packed = P
+        self._packed = {}
         self._par = sd
         self._versions = ver
+
+    def _logical_weight(self, name):
+        """(Cout,Cin,kh,kw) f32 weight (+bias) as the kernels see it: dead rows/columns removed, concat padding added."""
+        m = self._model()
+        n, A = m.n_feats, m.ACNum
+        w = self._par[name + ".weight"].detach()
+        b = self._par.get(name + ".bias")
+        if name == "MGAA.F.1":          # only the F1 half of every iteration's 2*3n kernel channels is ever read
+            rows = torch.cat([torch.arange(i * 6 * n, i * 6 * n + 3 * n) for i in range(A)]).to(w.device)
+            return w[rows], b.detach()[rows].contiguous()
+        if name == "MGAA.convcorr.0":   # drop the 2 zero-flow inputs, pad corr 81 -> 84 channels (16-byte pixels)
+            wp = torch.zeros(w.shape[0], 2 * n + 84, 1, 1, device=w.device, dtype=torch.float32)
+            wp[:, : 2 * n + 81] = w[:, : 2 * n + 81]
+            return wp, None
+        return w, (b.detach() if b is not None else None)
+
+    def _weights(self, name, kind):
+        """kind: 'direct' (f32 [taps][cin][cout16]) | torch.bfloat16 | torch.float16 (MFMA layout)."""
+        key = (name, kind)
+        if key not in self._packed:
+            w, b = self._logical_weight(name)
+            pk = hip.pack_conv_weight(w) if kind == "direct" else hip.pack_conv_weight_mfma(w, kind)
+            self._packed[key] = (pk, b, w.shape[0], w.shape[-1])
+        return self._packed[key]
 
     def _mask(self, Q, H, W, dev):
         key = (Q, H, W, str(dev))
@@ -99,20 +116,28 @@ class Engine:
         return self._dev_masks[key]
 
     # ---------------------------------------------------------------------------------------------- helpers
-    def _conv(self, name, srcs, dst, *, k=None, stride=1, act=ACT_NONE, slope=0.0, slope_t=None, res=(), res_scale=(),
-              ps=False, bias=True, cout=None):
-        m = self._model()
-        w = self._packed[name + ".weight"]
-        par = self._par
-        if name == "MGAA.F.1":
-            b = self._packed["MGAA.F.1.bias"]
-        else:
-            b = par.get(name + ".bias") if bias else None
-        wt = par[name + ".weight"]
-        ksz = wt.shape[-1] if k is None else k
-        co = (wt.shape[0] if cout is None else cout)
-        return hip.conv2d(srcs, w, ksz, co, dst, bias=b, stride=stride, act=act, slope=slope, slope_t=slope_t, res=res,
-                          res_scale=res_scale, pixel_shuffle=ps)
+    def _conv(self, name, srcs, dst, *, stride=1, act=ACT_NONE, slope=0.0, slope_t=None, res=(), res_scale=(),
+              ps=False, freq=False, direct=False):
+        self._convg(name, [dict(srcs=srcs, dst=dst, res=res, ps=ps)], stride=stride, act=act, slope=slope,
+                    slope_t=slope_t, res_scale=res_scale, ps=ps, freq=freq, direct=direct)
+        return dst
+
+    def _convg(self, name, groups, *, stride=1, act=ACT_NONE, slope=0.0, slope_t=None, res_scale=(), ps=False,
+               freq=False, direct=False):
+        """One conv layer applied to 1..3 tensors that share its weights (pyramid levels): a single grouped MFMA launch in
+        the 16-bit modes, per-tensor exact-f32 direct launches otherwise."""
+        ksz = self._par[name + ".weight"].shape[-1]
+        if self.precision != "f32" and not direct and hip.mfma_eligible(ksz, stride, groups):
+            # spectra are unnormalised (|DC| ~ H*W*mean can exceed the f16 range): frequency-domain layers use bf16
+            dt = torch.bfloat16 if (self.precision == "bf16" or freq) else torch.float16
+            w, b, cout, _ = self._weights(name, dt)
+            hip.conv2d_mfma(groups, w, ksz, cout, hip.BF16 if dt == torch.bfloat16 else hip.F16, bias=b, act=act,
+                            slope=slope, slope_t=slope_t, res_scale=res_scale, pixel_shuffle=ps)
+            return
+        w, b, cout, _ = self._weights(name, "direct")
+        for g in groups:
+            hip.conv2d(g["srcs"], w, ksz, cout, g["dst"], bias=b, stride=stride, act=act, slope=slope, slope_t=slope_t,
+                       res=g.get("res", ()), res_scale=res_scale, pixel_shuffle=ps)
 
     def _tap(self, name, t_nhwc):
         if self.taps is not None:
@@ -164,13 +189,13 @@ class Engine:
         t0 = self._new(dev, B, H, Wf, 2 * n)
         t1 = self._new(dev, B, H, Wf, 2 * n)
         for d, xa in enumerate((x1f, x3f)):
-            self._conv("MGAA.convfuse.0", [xa, x2f], t0, act=ACT_RELU)
-            self._conv("MGAA.convfuse.2", [t0], t1, act=ACT_RELU)
-            self._conv("MGAA.convfuse.4", [t1], off[d * B:(d + 1) * B], res=[xa, x2f], res_scale=[1.0, -1.0])
+            self._conv("MGAA.convfuse.0", [xa, x2f], t0, act=ACT_RELU, freq=True)
+            self._conv("MGAA.convfuse.2", [t0], t1, act=ACT_RELU, freq=True)
+            self._conv("MGAA.convfuse.4", [t1], off[d * B:(d + 1) * B], res=[xa, x2f], res_scale=[1.0, -1.0], freq=True)
         s0 = self._new(dev, B, H, Wf, n)
         sim = self._new(dev, B, H, Wf, 4)
-        self._conv("MGAA.convcrt.0", [x2f], s0, act=ACT_RELU)
-        self._conv("MGAA.convcrt.2", [s0], sim)
+        self._conv("MGAA.convcrt.0", [x2f], s0, act=ACT_RELU, freq=True)
+        self._conv("MGAA.convcrt.2", [s0], sim, freq=True)
 
         corr = self._new(dev, B, H, Wf, 84)                      # 81 live channels + 3 zero pad (16-byte pixels)
         cv = view(corr)
@@ -180,9 +205,9 @@ class Engine:
         c1 = self._new(dev, 2 * B, H, Wf, n)
         off4 = self._new(dev, 2 * B, H, Wf, 4)
         for d in range(2):
-            self._conv("MGAA.convcorr.0", [off[d * B:(d + 1) * B], corr], c0[d * B:(d + 1) * B], act=ACT_RELU)
-        self._conv("MGAA.convcorr.2", [c0], c1, act=ACT_RELU)
-        self._conv("MGAA.convcorr.4", [c1], off4)
+            self._conv("MGAA.convcorr.0", [off[d * B:(d + 1) * B], corr], c0[d * B:(d + 1) * B], act=ACT_RELU, freq=True)
+        self._conv("MGAA.convcorr.2", [c0], c1, act=ACT_RELU, freq=True)
+        self._conv("MGAA.convcorr.4", [c1], off4, freq=True)
 
         # A multi-scale ConvBlk heads -> (real, imag) planes -> irfft2 -> pixel offsets
         ospec = self._new(dev, B, H, Wf, 8 * A)                  # re: [0,4A), im: [4A,8A); channel = (dir*A+i)*2 + j
@@ -190,8 +215,8 @@ class Engine:
         u = self._new(dev, 2 * B, H, Wf, 4)
         for i in range(A):
             pre = f"MGAA.MConvB.{i}"
-            self._conv(pre + ".conv1", [off4], tt, act=ACT_PRELU, slope_t=par[pre + ".relu.weight"])
-            self._conv(pre + ".conv2", [tt], u)
+            self._conv(pre + ".conv1", [off4], tt, act=ACT_PRELU, slope_t=par[pre + ".relu.weight"], direct=True)
+            self._conv(pre + ".conv2", [tt], u, direct=True)
             gate = self._ca_gate(self._channel_sum(u), 1.0 / (H * Wf), pre + ".CA", 2 * B, 4)
             check(L.fcvsr_convblk_tail(u.data_ptr(), gate.data_ptr(), sim.data_ptr(), B, 2, H, Wf, ospec.data_ptr(),
                                        8 * A, 0, 4 * A, A, i, st), "fcvsr_convblk_tail")
@@ -206,7 +231,7 @@ class Engine:
         K = self._new(dev, B, H, W, A * 3 * n)
         self._conv("MGAA.conv_KP", [x2], kp)
         self._conv("MGAA.F.0", [kp], k0)
-        self._conv("MGAA.F.1", [k0], K, cout=A * 3 * n)
+        self._conv("MGAA.F.1", [k0], K)
 
         # iterative alignment: warp -> SAC(kernel1 twice) -> + feat_in -> LeakyReLU(0.1)
         al = self._new(dev, B, H, W, 2 * n)
@@ -299,18 +324,23 @@ class Engine:
         L = lib()
         st = stream_ptr()
         par = self._par
+        def like(x, c):
+            return self._new(x.device, x.shape[0], x.shape[1], x.shape[2], c)
+
+        # the four 3x3 convs of the block run once per layer over all three pyramid levels (shared weights, one launch)
+        t1 = [like(x, 2 * n) for x in xs]
+        t2 = [like(x, n) for x in xs]
+        r1 = [like(x, n) for x in xs]
+        rr = [like(x, n) for x in xs]
+        self._convg(pre + ".body.0", [dict(srcs=[x], dst=t) for x, t in zip(xs, t1)], act=ACT_LEAKY, slope=0.1)
+        self._convg(pre + ".body.2", [dict(srcs=[a], dst=t) for a, t in zip(t1, t2)])
+        self._convg(pre + ".RCB.body.0", [dict(srcs=[a], dst=t) for a, t in zip(t2, r1)], act=ACT_LEAKY, slope=0.2)
+        self._convg(pre + ".RCB.body.2", [dict(srcs=[a], dst=t) for a, t in zip(r1, rr)])
         R = []
-        for x in xs:
+        for l, x in enumerate(xs):
             dev = x.device
             B, H, W, _ = x.shape
-            t1 = self._new(dev, B, H, W, 2 * n)
-            t2 = self._new(dev, B, H, W, n)
-            r1 = self._new(dev, B, H, W, n)
-            r = self._new(dev, B, H, W, n)
-            self._conv(pre + ".body.0", [x], t1, act=ACT_LEAKY, slope=0.1)
-            self._conv(pre + ".body.2", [t1], t2)
-            self._conv(pre + ".RCB.body.0", [t2], r1, act=ACT_LEAKY, slope=0.2)
-            self._conv(pre + ".RCB.body.2", [r1], r)
+            r = rr[l]
             add = self._new(dev, B, n)
             nblk = (H * W + 255) // 256
             scratch = self._new(dev, B * nblk * (n + 2))
@@ -319,11 +349,13 @@ class Engine:
                                      par[pre + ".RCB.gcnet.channel_add_conv.2.weight"].data_ptr(), B, H, W, n,
                                      add.data_ptr(), scratch.data_ptr(), scratch.numel(), st), "fcvsr_gc_context")
             Rl = self._new(dev, B, H, W, n)
-            check(L.fcvsr_gc_apply(r.data_ptr(), add.data_ptr(), t2.data_ptr(), Rl.data_ptr(), 0.2, B, H, W, n, st),
+            check(L.fcvsr_gc_apply(r.data_ptr(), add.data_ptr(), t2[l].data_ptr(), Rl.data_ptr(), 0.2, B, H, W, n, st),
                   "fcvsr_gc_apply")
             R.append(Rl)
-        dn = [self._conv(pre + ".down.0", [R[l]], torch.empty_like(R[l])) for l in (0, 1)]
-        up = [self._conv(pre + ".up.0", [R[l]], torch.empty_like(R[l])) for l in (1, 2)]
+        dn = [torch.empty_like(R[l]) for l in (0, 1)]
+        up = [torch.empty_like(R[l]) for l in (1, 2)]
+        self._convg(pre + ".down.0", [dict(srcs=[R[l]], dst=dn[l]) for l in (0, 1)])
+        self._convg(pre + ".up.0", [dict(srcs=[R[l]], dst=up[l - 1]) for l in (1, 2)])
         outs = []
         for l, x in enumerate(xs):
             B, H, W, _ = x.shape
@@ -344,12 +376,10 @@ class Engine:
             for k in range(3):
                 t = self._block_rcb(f"recorb1.body.{g}.body.{k}", t)
             last = g == m.SCGroupN - 1
-            nxt = []
-            for l in range(3):
-                y = torch.empty_like(cur[l])
-                res = [cur[l], xs[l]] if last else [cur[l]]       # fold SCNetbk's outer skip into the last group conv
-                self._conv(f"recorb1.body.{g}.conv", [t[l]], y, res=res)
-                nxt.append(y)
+            nxt = [torch.empty_like(c) for c in cur]
+            # fold SCNetbk's outer skip (x + body(x), :817-821) into the last group conv's epilogue
+            grp = [dict(srcs=[t[l]], dst=nxt[l], res=([cur[l], xs[l]] if last else [cur[l]])) for l in range(3)]
+            self._convg(f"recorb1.body.{g}.conv", grp)
             cur = nxt
         return cur
 

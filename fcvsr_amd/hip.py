@@ -54,6 +54,7 @@ SIGNATURES = {
     "fcvsr_abi_version": [],
     "fcvsr_device_count": [],
     "fcvsr_conv2d": [C.POINTER(ConvDesc), _VP],
+    "fcvsr_conv2d_mfma": [C.POINTER(ConvDesc), _I, _I, _VP],
     "fcvsr_rfft2": [_PV, _I, _I, _I, _I, _VP, _I64, _I, _I, _VP],
     "fcvsr_irfft2": [_VP, _I64, _I, _I, _I, _I, _I, _I, _VP, _VP, _PV, _VP],
     "fcvsr_corr_lookup": [_VP, _VP, _I64, _I, _I, _I, _I, _I, _PV, _VP],
@@ -120,12 +121,17 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     return out.contiguous()
 
 
-def conv2d(srcs: Sequence[torch.Tensor], wpacked: torch.Tensor, ksize: int, cout: int, dst: torch.Tensor, *,
-           bias: Optional[torch.Tensor] = None, stride: int = 1, act: int = ACT_NONE, slope: float = 0.0,
-           slope_t: Optional[torch.Tensor] = None, res: Sequence[torch.Tensor] = (),
-           res_scale: Sequence[float] = (), pixel_shuffle: bool = False) -> torch.Tensor:
-    """srcs / res / dst are (b,y,x,c)-ordered tensors (any strides)."""
-    d = ConvDesc()
+def pack_conv_weight_mfma(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """(Cout, Cin, kh, kw) -> 16-bit [kh*kw][ceil128(Cout)][ceil64(Cin)], zero padded (layout of fcvsr_conv2d_mfma)."""
+    cout, cin, kh, kw = w.shape
+    cop, cip = (cout + 127) // 128 * 128, (cin + 63) // 64 * 64
+    out = torch.zeros(kh * kw, cop, cip, dtype=dtype, device=w.device)
+    out[:, :cout, :cin] = w.detach().float().permute(2, 3, 0, 1).reshape(kh * kw, cout, cin).to(dtype)
+    return out.contiguous()
+
+
+def _fill_desc(d: "ConvDesc", srcs, wpacked, ksize, cout, cout_pad, dst, bias, stride, act, slope, slope_t, res,
+               res_scale, pixel_shuffle) -> int:
     d.n_src = len(srcs)
     for i, s in enumerate(srcs):
         d.src[i] = view(s)
@@ -135,9 +141,7 @@ def conv2d(srcs: Sequence[torch.Tensor], wpacked: torch.Tensor, ksize: int, cout
     d.pad = ksize // 2
     d.cout = cout
     d.weight = wpacked.data_ptr()
-    d.cout_pad = wpacked.shape[-1]
-    cin = sum(s.shape[3] for s in srcs)
-    assert wpacked.shape[0] == ksize * ksize and wpacked.shape[1] == cin, (wpacked.shape, ksize, cin)
+    d.cout_pad = cout_pad
     d.bias = ptr(bias)
     d.act = act
     d.slope = slope
@@ -148,6 +152,58 @@ def conv2d(srcs: Sequence[torch.Tensor], wpacked: torch.Tensor, ksize: int, cout
         d.res_scale[i] = res_scale[i] if i < len(res_scale) else 1.0
     d.dst = view(dst)
     d.pixel_shuffle = int(pixel_shuffle)
+    return sum(s.shape[3] for s in srcs)
+
+
+def mfma_eligible(ksize: int, stride: int, groups) -> bool:
+    """Can fcvsr_conv2d_mfma take this problem? (1x1/3x3, stride 1, channel-contiguous 16-byte-aligned f32 inputs)"""
+    if ksize not in (1, 3) or stride != 1:
+        return False
+    for g in groups:
+        for s in g["srcs"]:
+            sb, sy, sx, sc = s.stride()
+            if s.dtype != torch.float32 or sc != 1 or s.shape[3] % 4 or sx % 4 or sy % 4 or sb % 4 or s.data_ptr() % 16:
+                return False
+            if ksize == 1 and (sy != sx * s.shape[2] or (s.shape[0] > 1 and sb != sy * s.shape[1])):
+                return False
+        for t in list(g.get("res", ())) + ([] if g.get("ps") else [g["dst"]]):
+            sb, sy, sx, sc = t.stride()
+            if ksize == 1 and (sy != sx * t.shape[2] or (t.shape[0] > 1 and sb != sy * t.shape[1])):
+                return False
+    return True
+
+
+def conv2d_mfma(groups, wpacked: torch.Tensor, ksize: int, cout: int, mma_dtype: int, *,
+                bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, slope: float = 0.0,
+                slope_t: Optional[torch.Tensor] = None, res_scale: Sequence[float] = (), pixel_shuffle: bool = False):
+    """groups: 1..3 dicts {srcs: [..], dst: t, res: [..]} sharing weights / epilogue (one launch)."""
+    n = len(groups)
+    descs = (ConvDesc * n)()
+    flops = 0.0
+    for i, g in enumerate(groups):
+        cin = _fill_desc(descs[i], g["srcs"], wpacked, ksize, cout, wpacked.shape[1], g["dst"], bias, 1, act, slope,
+                         slope_t, g.get("res", ()), res_scale, pixel_shuffle)
+        assert wpacked.shape[0] == ksize * ksize and wpacked.shape[2] >= cin, (wpacked.shape, ksize, cin)
+        flops += 2.0 * descs[i].B * descs[i].H * descs[i].W * cout * cin * ksize * ksize
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().fcvsr_conv2d_mfma(descs, n, mma_dtype, stream_ptr()), "fcvsr_conv2d_mfma")
+        e1.record()
+        PROFILE.append((e0, e1, flops, "mfma"))
+        return
+    check(lib().fcvsr_conv2d_mfma(descs, n, mma_dtype, stream_ptr()), "fcvsr_conv2d_mfma")
+
+
+def conv2d(srcs: Sequence[torch.Tensor], wpacked: torch.Tensor, ksize: int, cout: int, dst: torch.Tensor, *,
+           bias: Optional[torch.Tensor] = None, stride: int = 1, act: int = ACT_NONE, slope: float = 0.0,
+           slope_t: Optional[torch.Tensor] = None, res: Sequence[torch.Tensor] = (),
+           res_scale: Sequence[float] = (), pixel_shuffle: bool = False) -> torch.Tensor:
+    """srcs / res / dst are (b,y,x,c)-ordered tensors (any strides)."""
+    d = ConvDesc()
+    cin = _fill_desc(d, srcs, wpacked, ksize, cout, wpacked.shape[-1], dst, bias, stride, act, slope, slope_t, res,
+                     res_scale, pixel_shuffle)
+    assert wpacked.shape[0] == ksize * ksize and wpacked.shape[1] == cin, (wpacked.shape, ksize, cin)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -155,7 +211,7 @@ def conv2d(srcs: Sequence[torch.Tensor], wpacked: torch.Tensor, ksize: int, cout
         e1.record()
         ho = (d.H + 2 * d.pad - d.kh) // stride + 1
         wo = (d.W + 2 * d.pad - d.kw) // stride + 1
-        PROFILE.append((e0, e1, 2.0 * d.B * ho * wo * cout * cin * ksize * ksize))
+        PROFILE.append((e0, e1, 2.0 * d.B * ho * wo * cout * cin * ksize * ksize, "direct"))
         return dst
     check(lib().fcvsr_conv2d(C.byref(d), stream_ptr()), "fcvsr_conv2d")
     return dst

@@ -73,6 +73,13 @@ int  fcvsr_device_count(void);
 /* direct (VALU, f32) convolution: any kernel size / channel count; used for skinny layers and as the exact-f32 path */
 int fcvsr_conv2d(const fcvsr_conv_desc* d, void* stream);
 
+/* Matrix-core (MFMA) implicit-GEMM convolution: 1x1 or 3x3, stride 1, "same" padding, f32 activations in HBM converted
+ * to `mma_dtype` (FCVSR_BF16 | FCVSR_F16) while staging through LDS, f32 accumulate and f32 epilogue.
+ * `descs[0..n_groups)` (1..3) are problems that share weights/epilogue but have their own tensors and sizes (the three
+ * pyramid levels of BlockRCB, CVSR_freq.py:766-777) and run in ONE launch.
+ * weight: 16-bit [kh*kw][cout_pad][cin_pad], cout_pad = ceil128(cout), cin_pad = ceil64(cin), zero padded. */
+int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int mma_dtype, void* stream);
+
 /* ---- frequency transforms: torch.fft.rfft2 / irfft2 (norm='backward') of NHWC channel groups -------------
  * Spectrum layout: buffer [B][H][Wf][pix_stride] with Wf=W/2+1; channel c of the group has its imaginary part at
  * channel im_off+c and its real part at re_off+c (the reference packs [imag, real], CVSR_freq.py:1456-1465).

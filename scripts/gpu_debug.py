@@ -6,6 +6,7 @@ import torch
 from helpers import CASES, load_case, weights_for
 from fcvsr_amd.arch import CVSR_freq as A
 
+prec = os.environ.get("FCVSR_PRECISION", "f32")
 cases = sys.argv[1:] or CASES
 for name in cases:
     x, gold, meta = load_case(name)
@@ -17,7 +18,10 @@ for name in cases:
         model._engine.taps = {}
         t = time.time(); y = model(x.cuda()); torch.cuda.synchronize(); dt = time.time() - t
     taps = model._engine.taps
-    print(f"== {name}: {dt*1e3:.1f} ms; out finite={bool(torch.isfinite(y).all())}")
+    mse = float(((y.cpu().double() - gold["out"].double()) * 255).pow(2).mean())
+    import math
+    print(f"== {name} [{prec}]: {dt*1e3:.1f} ms; out finite={bool(torch.isfinite(y).all())}; "
+          f"PSNR(build, reference) = {20*math.log10(255/math.sqrt(mse)) if mse > 0 else float('inf'):.2f} dB")
     for k, g in gold.items():
         if k not in taps:
             print(f"   {k:24s} (no tap)"); continue

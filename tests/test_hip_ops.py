@@ -1,0 +1,162 @@
+"""GPU: individual C-ABI entry points against plain PyTorch fp32 references of the same op."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(t):  # NCHW cpu -> NHWC cuda contiguous
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def _rand(*s, seed=0):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(s).astype(np.float32))
+
+
+@pytest.mark.parametrize("cin,cout,k,stride", [(7, 448, 3, 1), (64, 64, 3, 2), (4, 4, 7, 1), (64, 1, 3, 1), (84, 64, 3, 1)])
+def test_conv_direct_vs_torch(cin, cout, k, stride):
+    from fcvsr_amd import hip
+    x, w, b = _rand(2, cin, 20, 28), _rand(cout, cin, k, k, seed=1) * 0.1, _rand(cout, seed=2)
+    ref = F.leaky_relu(F.conv2d(x, w, b, stride=stride, padding=k // 2), 0.1)
+    Ho, Wo = ref.shape[2:]
+    dst = torch.empty(2, Ho, Wo, cout, device="cuda")
+    src = x.cuda().permute(0, 2, 3, 1) if cin == 7 else nhwc(x)       # cin=7: strided NCHW view, like feat_extract
+    hip.conv2d([src], hip.pack_conv_weight(w.cuda()), k, cout, dst, bias=b.cuda(), stride=stride, act=hip.ACT_LEAKY,
+               slope=0.1)
+    assert float((nchw(dst) - ref).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("cins,cout,k,ps", [([64], 128, 3, False), ([128], 64, 3, False), ([64, 16, 4], 64, 3, False),
+                                            ([64], 256, 1, True), ([64], 256, 3, True), ([128, 84], 64, 1, False),
+                                            ([64], 1, 3, False), ([64], 576, 1, False)])
+def test_conv_mfma_vs_torch(dt, cins, cout, k, ps):
+    """Reference = fp32 conv of the operands rounded to the MFMA dtype (exactly what the kernel multiplies)."""
+    from fcvsr_amd import hip
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    B, H, W = 2, 20, 44            # partial tiles in both directions; for 1x1 a flat tail (2*20*44 % 256 != 0)
+    xs = [_rand(B, c, H, W, seed=10 + i) for i, c in enumerate(cins)]
+    cin = sum(cins)
+    w, b = _rand(cout, cin, k, k, seed=3) / np.sqrt(cin * k * k), _rand(cout, seed=4)
+    res = _rand(B, cout, H, W, seed=5)
+    xr = torch.cat(xs, 1).to(tdt).float()
+    ref = F.conv2d(xr, w.to(tdt).float(), b, padding=k // 2)
+    ref = torch.where(ref >= 0, ref, 0.2 * ref) + 0.5 * res
+    if ps:
+        ref = F.pixel_shuffle(ref, 2)
+        dst = torch.empty(B, 2 * H, 2 * W, cout // 4, device="cuda")
+    elif cout == 1:
+        dst = torch.empty(B, cout, H, W, device="cuda").permute(0, 2, 3, 1)     # NCHW boundary view like conv_last0
+    else:
+        dst = torch.empty(B, H, W, cout, device="cuda")
+    g = dict(srcs=[nhwc(x) for x in xs], dst=dst, res=[nhwc(res)])
+    assert hip.mfma_eligible(k, 1, [g])
+    hip.conv2d_mfma([g], hip.pack_conv_weight_mfma(w.cuda(), tdt), k, cout, hip.BF16 if dt == "bf16" else hip.F16,
+                    bias=b.cuda(), act=hip.ACT_LEAKY, slope=0.2, res_scale=[0.5], pixel_shuffle=ps)
+    err = float((nchw(dst) - ref).abs().max())
+    assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
+
+
+def test_conv_mfma_grouped_levels():
+    from fcvsr_amd import hip
+    w = _rand(64, 64, 3, 3, seed=1) / 24
+    wp = hip.pack_conv_weight_mfma(w.cuda(), torch.bfloat16)
+    xs = [_rand(1, 64, h, ww, seed=h) for h, ww in [(36, 64), (18, 32), (9, 16)]]
+    groups = [dict(srcs=[nhwc(x)], dst=torch.empty(1, x.shape[2], x.shape[3], 64, device="cuda")) for x in xs]
+    hip.conv2d_mfma(groups, wp, 3, 64, hip.BF16)
+    for x, g in zip(xs, groups):
+        ref = F.conv2d(x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), padding=1)
+        assert float((nchw(g["dst"]) - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("H,W,n", [(180, 320, 64), (20, 24, 64), (144, 176, 16), (272, 480, 8), (17, 23, 5), (64, 64, 12)])
+def test_rfft2_irfft2_vs_torch(H, W, n):
+    """Any length incl. primes 11/17/23 (Vid4 / CVCP sizes) and odd W; [imag, real] packing; c2r semantics."""
+    from fcvsr_amd import hip
+    L = hip.lib()
+    x = _rand(1, n, H, W)
+    Wf = W // 2 + 1
+    src = nhwc(x)
+    spec = torch.zeros(1, H, Wf, 2 * n, device="cuda")
+    v = hip.view(src)
+    hip.check(L.fcvsr_rfft2(C.byref(v), 1, H, W, n, spec.data_ptr(), 2 * n, 0, n, hip.stream_ptr()), "rfft2")
+    X = torch.fft.rfft2(x.double())
+    ref = torch.cat([X.imag, X.real], 1).float()
+    scale = float(ref.abs().max())
+    assert float((nchw(spec) - ref).abs().max()) < 3e-6 * scale
+    # inverse of a NON-Hermitian-consistent spectrum (imag parts at DC/Nyquist must be ignored like torch's c2r)
+    sp = _rand(1, 2 * n, H, Wf, seed=9)
+    refi = torch.fft.irfft2(torch.complex(sp[:, n:].double(), sp[:, :n].double()), s=(H, W)).float()
+    spec2 = nhwc(sp)
+    dst = torch.empty(1, H, W, n, device="cuda")
+    dv = hip.view(dst)
+    hip.check(L.fcvsr_irfft2(spec2.data_ptr(), 2 * n, 0, n, 1, H, W, n, None, None, C.byref(dv), hip.stream_ptr()),
+              "irfft2")
+    assert float((nchw(dst) - refi).abs().max()) < 3e-6 * max(1.0, float(refi.abs().max()))
+
+
+def test_fft_roundtrip_full_size():
+    """Size-independent property at the benchmark size: irfft2(rfft2(x)) == x."""
+    from fcvsr_amd import hip
+    L = hip.lib()
+    B, H, W, n = 2, 180, 320, 64
+    src = torch.rand(B, H, W, n, device="cuda")
+    spec = torch.empty(B, H, W // 2 + 1, 2 * n, device="cuda")
+    dst = torch.empty_like(src)
+    v, dv = hip.view(src), hip.view(dst)
+    hip.check(L.fcvsr_rfft2(C.byref(v), B, H, W, n, spec.data_ptr(), 2 * n, 0, n, hip.stream_ptr()), "rfft2")
+    hip.check(L.fcvsr_irfft2(spec.data_ptr(), 2 * n, 0, n, B, H, W, n, None, None, C.byref(dv), hip.stream_ptr()), "irfft2")
+    assert float((dst - src).abs().max()) < 2e-6
+
+
+def test_corr_warp_sac_vs_oracle():
+    from fcvsr_amd import hip
+    from oracle import fcvsr_oracle as O
+    L = hip.lib()
+    st = hip.stream_ptr()
+    B, C2, H, Wf = 2, 128, 72, 19          # H > 68 exercises the row cut-off of the 64-row correlation image
+    a, b = _rand(B, C2, H, Wf, seed=1), _rand(B, C2, H, Wf, seed=2)
+    dst = torch.empty(B, H, Wf, 84, device="cuda")
+    dv = hip.view(dst)
+    ad, bd = nhwc(a), nhwc(b)      # keep the device tensors alive while the kernel runs
+    hip.check(L.fcvsr_corr_lookup(ad.data_ptr(), bd.data_ptr(), C2, B, H, Wf, C2, 4, C.byref(dv), st), "corr")
+    got = nchw(dst)
+    assert torch.equal(got[:, 81:], torch.zeros_like(got[:, 81:]))
+    assert float((got[:, :81] - O.corr_lookup(a, b)).abs().max()) < 1e-6
+    # warp + SAC
+    B, Cc, H, W = 1, 64, 24, 40
+    f, off, k1 = _rand(B, Cc, H, W, seed=3), _rand(B, 2, H, W, seed=4) * 3.0, _rand(B, 3 * Cc, H, W, seed=5)
+    fd, od, kd = nhwc(f), nhwc(off), nhwc(k1)
+    s = torch.empty_like(fd); vv = torch.empty_like(fd); out = torch.empty_like(fd)
+    fv, ov, kv, sv, vvv, outv = (hip.view(t) for t in (fd, od, kd, s, vv, out))
+    hip.check(L.fcvsr_warp(C.byref(fv), C.byref(ov), B, H, W, C.byref(sv), st), "warp")
+    hip.check(L.fcvsr_sac_v(C.byref(sv), C.byref(kv), B, H, W, C.byref(vvv), st), "sac_v")
+    hip.check(L.fcvsr_sac_h(C.byref(vvv), C.byref(kv), C.byref(fv), 0.1, B, H, W, C.byref(outv), st), "sac_h")
+    sref = O.warp_bilinear(f, off)
+    assert float((nchw(s) - sref).abs().max()) < 1e-5
+    ref = F.leaky_relu(O.sac_kernel1_twice(sref, k1) + f, 0.1)
+    assert float((nchw(out) - ref).abs().max()) < 1e-4
+
+
+def test_flow_warp_known_answer():
+    """The reference test-suite's own known answer for flow_warp (mmedit_train/tests/test_models/test_common/
+    test_flow_warp.py:32-46): flow = -1 everywhere == shift by one pixel with zero fill."""
+    from fcvsr_amd import hip
+    L = hip.lib()
+    x = torch.rand(1, 4, 10, 10)
+    off = -torch.ones(1, 2, 10, 10)
+    xd, od = nhwc(x), nhwc(off)
+    out = torch.empty_like(xd)
+    xv, ov, outv = hip.view(xd), hip.view(od), hip.view(out)
+    hip.check(L.fcvsr_warp(C.byref(xv), C.byref(ov), 1, 10, 10, C.byref(outv), hip.stream_ptr()), "warp")
+    ref = torch.zeros_like(x)
+    ref[:, :, 1:, 1:] = x[:, :, :-1, :-1]
+    assert float((nchw(out) - ref).abs().max()) < 1e-5

@@ -29,7 +29,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-constexpr int kTH = 8, kTW = 32, kCK = 64, kLD = kCK + 8;  // tile rows/cols, channel chunk, padded LDS row (halfwords)
+constexpr int kTW = 32, kCK = 64, kLD = kCK + 8;  // tile cols, channel chunk, padded LDS row (halfwords); tile rows = 4*MW
 
 struct MGroup {
   View src[3];
@@ -54,6 +54,7 @@ struct MfmaArgs {
   float rs[2];
   int ps;
   int flat;            // 1x1: treat pixels as a flat list of B*H*W
+  int src16, dst16;    // sources / destination stored in the MFMA dtype (16-bit) instead of f32
   int dbg;             // ablation switches for profiling builds (FCVSR_MFMA_DBG): 1 skip staging, 2 skip MFMA, 4 skip stores
 };
 
@@ -77,7 +78,7 @@ __device__ __forceinline__ f32x16_t mfma(uint4 a, uint4 b, f32x16_t c) {
 }
 
 struct EpiCtx {
-  int act, n_res, ps, flat, H, W, b;
+  int act, n_res, ps, flat, H, W, b, dst16, cq4;   // cq4 = cout/4 (pixel-shuffle: couts are ordered sub-pixel-major)
   float slope, rs0, rs1;
   long long npix;
   View res0, res1, dst;
@@ -85,6 +86,7 @@ struct EpiCtx {
 
 // Epilogue for one pixel x 4 consecutive output channels (n..n+3) held as a float4 (after the LDS transpose).
 // Element offsets are 32-bit (host checks every tensor spans < 2^31 elements).
+template <bool BF16>
 __device__ __forceinline__ void epilogue_quad(const EpiCtx& e, float4 v, const float* bias, int cout, int n, int py, int px,
                                               long long pflat) {
   const bool pok = e.flat ? (pflat < e.npix) : ((py < e.H) && (px < e.W));
@@ -105,55 +107,67 @@ __device__ __forceinline__ void epilogue_quad(const EpiCtx& e, float4 v, const f
     if (e.act == FCVSR_ACT_RELU) x[q] = fmaxf(x[q], 0.f);
     else if (e.act == FCVSR_ACT_LEAKY || e.act == FCVSR_ACT_PRELU) x[q] = x[q] >= 0.f ? x[q] : x[q] * e.slope;
   }
-  if (e.n_res > 0) {
-    const View& rv = e.res0;
-    const int o = (e.flat ? (int)pflat * (int)rv.sx : (e.b * (int)rv.sb + py * (int)rv.sy + px * (int)rv.sx));
-    if (full && rv.sc == 1) {
-      const float4 r4 = *reinterpret_cast<const float4*>(rv.p + o + n);
-      x[0] = fmaf(e.rs0, r4.x, x[0]); x[1] = fmaf(e.rs0, r4.y, x[1]); x[2] = fmaf(e.rs0, r4.z, x[2]); x[3] = fmaf(e.rs0, r4.w, x[3]);
-    } else {
+  // residual inputs are indexed by the ORIGINAL output channel: with pixel-shuffle packing row n = sp*(cout/4)+c is
+  // original channel 4c+sp
+  const int sp_r = e.ps ? n / e.cq4 : 0;
+  const int c_r = e.ps ? n - sp_r * e.cq4 : n;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) if (n + q < cout) x[q] = fmaf(e.rs0, rv.p[o + (n + q) * (int)rv.sc], x[q]);
-    }
-  }
-  if (e.n_res > 1) {
-    const View& rv = e.res1;
-    const int o = (e.flat ? (int)pflat * (int)rv.sx : (e.b * (int)rv.sb + py * (int)rv.sy + px * (int)rv.sx));
-    if (full && rv.sc == 1) {
-      const float4 r4 = *reinterpret_cast<const float4*>(rv.p + o + n);
-      x[0] = fmaf(e.rs1, r4.x, x[0]); x[1] = fmaf(e.rs1, r4.y, x[1]); x[2] = fmaf(e.rs1, r4.z, x[2]); x[3] = fmaf(e.rs1, r4.w, x[3]);
-    } else {
+  for (int ri = 0; ri < 2; ++ri) {
+    if (ri < e.n_res) {
+      const View& rv = ri == 0 ? e.res0 : e.res1;
+      const float rs = ri == 0 ? e.rs0 : e.rs1;
+      const int o = (e.flat ? (int)pflat * (int)rv.sx : (e.b * (int)rv.sb + py * (int)rv.sy + px * (int)rv.sx));
+      if (full && rv.sc == 1 && !e.ps) {
+        const float4 r4 = *reinterpret_cast<const float4*>(rv.p + o + n);
+        x[0] = fmaf(rs, r4.x, x[0]); x[1] = fmaf(rs, r4.y, x[1]); x[2] = fmaf(rs, r4.z, x[2]); x[3] = fmaf(rs, r4.w, x[3]);
+      } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) if (n + q < cout) x[q] = fmaf(e.rs1, rv.p[o + (n + q) * (int)rv.sc], x[q]);
+        for (int q = 0; q < 4; ++q) {
+          const int ch = e.ps ? 4 * (c_r + q) + sp_r : n + q;
+          if (n + q < cout) x[q] = fmaf(rs, rv.p[o + ch * (int)rv.sc], x[q]);
+        }
+      }
     }
   }
   const View& d = e.dst;
+  int o;
+  int nn = n;
   if (e.ps) {
-    // n..n+3 = the 2x2 sub-pixels (i,j) of output channel n/4 (cout % 4 == 0 is checked on the host)
+    // pixel-shuffle: the host orders output channels sub-pixel-major, n = (2*i+j)*(cout/4) + c, so a lane's 4 consecutive
+    // couts are 4 consecutive channels c of the same sub-pixel (i,j): one vector store at pixel (2y+i, 2x+j).
     int qy = py, qx = px, qb = e.b;
     if (e.flat) {
       qx = (int)(pflat % e.W);
       qy = (int)((pflat / e.W) % e.H);
       qb = (int)(pflat / ((long long)e.W * e.H));
     }
-    float* dp = d.p + qb * (int)d.sb + (2 * qy) * (int)d.sy + (2 * qx) * (int)d.sx + (n >> 2) * (int)d.sc;
-    dp[0] = x[0];
-    dp[(int)d.sx] = x[1];
-    dp[(int)d.sy] = x[2];
-    dp[(int)d.sy + (int)d.sx] = x[3];
+    const int sp = n / e.cq4;
+    nn = n - sp * e.cq4;
+    o = qb * (int)d.sb + (2 * qy + (sp >> 1)) * (int)d.sy + (2 * qx + (sp & 1)) * (int)d.sx;
   } else {
-    const int o = (e.flat ? (int)pflat * (int)d.sx : (e.b * (int)d.sb + py * (int)d.sy + px * (int)d.sx));
+    o = (e.flat ? (int)pflat * (int)d.sx : (e.b * (int)d.sb + py * (int)d.sy + px * (int)d.sx));
+  }
+  if (e.dst16) {
+    uint16_t* dp = reinterpret_cast<uint16_t*>(d.p);
+    const uint2 pk = cvt4<BF16>(make_float4(x[0], x[1], x[2], x[3]));
     if (full && d.sc == 1) {
-      *reinterpret_cast<float4*>(d.p + o + n) = make_float4(x[0], x[1], x[2], x[3]);
+      *reinterpret_cast<uint2*>(dp + o + nn) = pk;
     } else {
+      const uint16_t hv[4] = {(uint16_t)(pk.x & 0xffff), (uint16_t)(pk.x >> 16), (uint16_t)(pk.y & 0xffff), (uint16_t)(pk.y >> 16)};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) if (n + q < cout) d.p[o + (n + q) * (int)d.sc] = x[q];
+      for (int q = 0; q < 4; ++q) if (n + q < cout) dp[o + (nn + q) * (int)d.sc] = hv[q];
     }
+  } else if (full && d.sc == 1) {
+    *reinterpret_cast<float4*>(d.p + o + nn) = make_float4(x[0], x[1], x[2], x[3]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (n + q < cout) d.p[o + (nn + q) * (int)d.sc] = x[q];
   }
 }
 
-template <bool BF16, int NT, int KS>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(MfmaArgs a) {
+template <bool BF16, int NT, int KS, int MW>
+__global__ __launch_bounds__(256, MW == 1 ? 4 : 2) void conv_mfma_kernel(MfmaArgs a) {
+  constexpr int kTH = 4 * MW;                       // MW tile rows (M-fragments) per wave
   constexpr int PAD = KS / 2;
   constexpr int HH = kTH + 2 * PAD, HWD = kTW + 2 * PAD;
   constexpr int NF = NT / 32;
@@ -189,9 +203,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(MfmaArgs a) {
     tx0 = (t2 % G.tiles_x) * kTW;
   }
 
-  f32x16_t acc[2][NF];
+  f32x16_t acc[MW][NF];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MW; ++m)
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
@@ -201,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(MfmaArgs a) {
     const int ck = (a.cin16 - c0) < kCK ? (a.cin16 - c0) : kCK;       // multiple of 16
     __syncthreads();   // every wave is done reading A_s / B_s of the previous chunk
     // ---- stage the halo tile of channels [c0, c0+64): f32 HBM -> 16-bit LDS -------------------------------------------
-    {
+    if (!a.src16) {
       constexpr int NHP = HH * HWD;                    // halo pixels
       constexpr int ITERS = (NHP * 16 + 255) / 256;    // 16 channel-quads per pixel, 256 threads
       const int q = tid & 15;
@@ -237,6 +251,43 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(MfmaArgs a) {
           if (hp < NHP) *reinterpret_cast<uint2*>(A_s + hp * kLD + q * 4) = cvt4<BF16>(v[u]);
         }
       }
+    } else {
+      // sources already stored in the MFMA dtype: straight 16-byte copies (8 channels per lane, 8 lanes per pixel)
+      constexpr int NHP = HH * HWD;
+      constexpr int ITERS = (NHP * 8 + 255) / 256;
+      const int q = tid & 7;
+      const int c = c0 + q * 8;
+      const bool cok = (c < a.cin_total) && !(a.dbg & 1);
+      int s_ = 0, cl = c;
+      if (cl >= a.seg_c[0]) { cl -= a.seg_c[0]; s_ = 1; if (cl >= a.seg_c[1]) { cl -= a.seg_c[1]; s_ = 2; } }
+      const View sv = G.src[cok ? s_ : 0];
+      const uint16_t* sbase = reinterpret_cast<const uint16_t*>(sv.p) + (a.flat ? 0ll : (long long)b * sv.sb) + cl;
+      constexpr int UNR = 8;
+#pragma unroll 1
+      for (int it0 = 0; it0 < ITERS; it0 += UNR) {
+        uint4 v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int hp = (tid >> 3) + (it0 + u) * 32;
+          v[u] = make_uint4(0, 0, 0, 0);
+          if (cok && hp < NHP) {
+            if (a.flat) {
+              const long long p = flat0 + hp;
+              if (p < npix) v[u] = *reinterpret_cast<const uint4*>(sbase + p * sv.sx);
+            } else {
+              const int hy = hp / HWD, hx = hp - hy * HWD;
+              const int iy = ty0 + hy - PAD, ix = tx0 + hx - PAD;
+              if (iy >= 0 && iy < G.H && ix >= 0 && ix < G.W)
+                v[u] = *reinterpret_cast<const uint4*>(sbase + (long long)iy * sv.sy + (long long)ix * sv.sx);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int hp = (tid >> 3) + (it0 + u) * 32;
+          if (hp < NHP) *reinterpret_cast<uint4*>(A_s + hp * kLD + q * 8) = v[u];
+        }
+      }
     }
     // ---- taps: weights global -> regs -> LDS, then MFMA ---------------------------------------------------------------
     uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;   // named (not an array): must stay in VGPRs
@@ -267,18 +318,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(MfmaArgs a) {
       __syncthreads();                   // A_s (first tap) and B_s visible
       if (tap + 1 < KS * KS) FCVSR_FETCH_W(tap + 1);
       const int ky = tap / KS, kx = tap - ky * KS;
-      const uint16_t* arow0 = A_s + ((2 * wave + ky) * HWD + r + kx) * kLD + h * 8;
+      const uint16_t* arow0 = A_s + ((MW * wave + ky) * HWD + r + kx) * kLD + h * 8;
       const uint16_t* brow = B_s + r * kLD + h * 8;
 #pragma unroll
       for (int kk = 0; kk < kCK / 16; ++kk) {
         if (kk * 16 < ck && !(a.dbg & 2)) {
-          uint4 af[2], bf[NF];
-          af[0] = *reinterpret_cast<const uint4*>(arow0 + kk * 16);
-          af[1] = *reinterpret_cast<const uint4*>(arow0 + HWD * kLD + kk * 16);
+          uint4 af[MW], bf[NF];
+#pragma unroll
+          for (int m = 0; m < MW; ++m) af[m] = *reinterpret_cast<const uint4*>(arow0 + m * HWD * kLD + kk * 16);
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf) bf[nf] = *reinterpret_cast<const uint4*>(brow + nf * 32 * kLD + kk * 16);
 #pragma unroll
-          for (int m = 0; m < 2; ++m)
+          for (int m = 0; m < MW; ++m)
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) acc[m][nf] = mfma<BF16>(af[m], bf[nf], acc[m][nf]);
         }
@@ -295,14 +346,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(MfmaArgs a) {
   EpiCtx e;
   e.act = a.act; e.slope = slope; e.n_res = a.n_res; e.rs0 = a.rs[0]; e.rs1 = a.rs[1]; e.ps = a.ps; e.flat = a.flat;
   e.res0 = G.res[0]; e.res1 = G.res[1]; e.dst = G.dst; e.H = G.H; e.W = G.W; e.b = b; e.npix = npix;
+  e.dst16 = a.dst16; e.cq4 = a.cout >> 2;
   constexpr int EW = NT >= 64 ? 64 : 32;        // couts per pass
   constexpr int EROW = EW + 4;                  // padded row (floats): conflict-free b32 writes and b128 reads
   constexpr int QPR = EW / 4;                   // float4 per pixel row
   __syncthreads();                              // every wave is done with A_s / B_s
   float* E_s = reinterpret_cast<float*>(lds) + wave * (32 * EROW);
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int yo = 2 * wave + m;
+  for (int m = 0; m < MW; ++m) {
+    const int yo = MW * wave + m;
 #pragma unroll
     for (int nh = 0; nh < NT / EW; ++nh) {
 #pragma unroll
@@ -318,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(MfmaArgs a) {
         const int cq = idx % QPR, p = idx / QPR;
         const float4 v = *reinterpret_cast<const float4*>(E_s + p * EROW + cq * 4);
         if (!(a.dbg & 4) || v.x == 12345.678f)
-          epilogue_quad(e, v, a.bias, a.cout, n0 + nh * EW + cq * 4, ty0 + yo, tx0 + p, flat0 + yo * kTW + p);
+          epilogue_quad<BF16>(e, v, a.bias, a.cout, n0 + nh * EW + cq * 4, ty0 + yo, tx0 + p, flat0 + yo * kTW + p);
         asm volatile("" ::: "memory");
       }
       __builtin_amdgcn_wave_barrier();
@@ -326,31 +378,39 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(MfmaArgs a) {
   }
 }
 
-template <bool BF16, int NT, int KS>
+template <bool BF16, int NT, int KS, int MW>
 static hipError_t launch_mfma(const MfmaArgs& a, int total_tiles, hipStream_t st) {
   constexpr int PAD = KS / 2;
-  const size_t lds = ((size_t)(kTH + 2 * PAD) * (kTW + 2 * PAD) * kLD + (size_t)NT * kLD) * sizeof(uint16_t);
+  constexpr int kTH = 4 * MW;
+  size_t lds = ((size_t)(kTH + 2 * PAD) * (kTW + 2 * PAD) * kLD + (size_t)NT * kLD) * sizeof(uint16_t);
+  const size_t epi = 4ull * 32 * ((NT >= 64 ? 64 : 32) + 4) * sizeof(float);     // epilogue transpose area
+  if (lds < epi) lds = epi;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_mfma_kernel<BF16, NT, KS>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_mfma_kernel<BF16, NT, KS, MW>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_mfma_kernel<BF16, NT, KS>), dim3(total_tiles * a.n_nblk), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<BF16, NT, KS, MW>), dim3(total_tiles * a.n_nblk), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
-template <bool BF16>
-static hipError_t dispatch(const MfmaArgs& a, int nt, int ks, int total_tiles, hipStream_t st) {
+template <bool BF16, int MW>
+static hipError_t dispatch2(const MfmaArgs& a, int nt, int ks, int total_tiles, hipStream_t st) {
   if (ks == 3) {
-    if (nt == 128) return launch_mfma<BF16, 128, 3>(a, total_tiles, st);
-    if (nt == 64) return launch_mfma<BF16, 64, 3>(a, total_tiles, st);
-    return launch_mfma<BF16, 32, 3>(a, total_tiles, st);
+    if (nt == 128) return launch_mfma<BF16, 128, 3, MW>(a, total_tiles, st);
+    if (nt == 64) return launch_mfma<BF16, 64, 3, MW>(a, total_tiles, st);
+    return launch_mfma<BF16, 32, 3, MW>(a, total_tiles, st);
   }
-  if (nt == 128) return launch_mfma<BF16, 128, 1>(a, total_tiles, st);
-  if (nt == 64) return launch_mfma<BF16, 64, 1>(a, total_tiles, st);
-  return launch_mfma<BF16, 32, 1>(a, total_tiles, st);
+  if (nt == 128) return launch_mfma<BF16, 128, 1, MW>(a, total_tiles, st);
+  if (nt == 64) return launch_mfma<BF16, 64, 1, MW>(a, total_tiles, st);
+  return launch_mfma<BF16, 32, 1, MW>(a, total_tiles, st);
+}
+
+template <bool BF16>
+static hipError_t dispatch(const MfmaArgs& a, int nt, int ks, int mw, int total_tiles, hipStream_t st) {
+  return mw == 1 ? dispatch2<BF16, 1>(a, nt, ks, total_tiles, st) : dispatch2<BF16, 2>(a, nt, ks, total_tiles, st);
 }
 
 }  // namespace fcvsr
@@ -359,12 +419,16 @@ using namespace fcvsr;
 
 // channel-contiguous res/dst views are accessed 16 bytes at a time
 static bool vec_view_ok(const fcvsr_view& v) {
-  return v.sc != 1 || v.c < 4 || (v.sx % 4 == 0 && v.sy % 4 == 0 && v.sb % 4 == 0 && ((uintptr_t)v.ptr % 16) == 0);
+  const int g = v.dtype == FCVSR_F32 ? 4 : 8;   // 16-byte granules for f32 quads, 8-byte for 16-bit quads (keep 16 for safety)
+  return v.sc != 1 || v.c < 4 || (v.sx % 4 == 0 && v.sy % 4 == 0 && v.sb % 4 == 0 && ((uintptr_t)v.ptr % (g == 4 ? 16 : 8)) == 0);
 }
 
-static bool src_ok(const fcvsr_view& v) {
-  return v.ptr && v.dtype == FCVSR_F32 && v.sc == 1 && v.c % 4 == 0 && v.sx % 4 == 0 && v.sy % 4 == 0 && v.sb % 4 == 0 &&
-         ((uintptr_t)v.ptr % 16) == 0;
+// sources: f32 (converted while staging, 4 channels = 16 bytes per lane) or already in the MFMA dtype (8 channels per lane)
+static bool src_ok(const fcvsr_view& v, int mma_dtype) {
+  if (!v.ptr || v.sc != 1 || ((uintptr_t)v.ptr % 16) != 0) return false;
+  const int g = v.dtype == FCVSR_F32 ? 4 : 8;
+  if (v.dtype != FCVSR_F32 && v.dtype != mma_dtype) return false;
+  return v.c % g == 0 && v.sx % g == 0 && v.sy % g == 0 && v.sb % g == 0;
 }
 
 extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int mma_dtype, void* stream) {
@@ -376,8 +440,10 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   FCVSR_CHECK_ARG(d0.n_src >= 1 && d0.n_src <= 3 && d0.n_res >= 0 && d0.n_res <= 2 && d0.cout > 0, "bad descriptor");
   FCVSR_CHECK_ARG(d0.weight != nullptr && d0.cout_pad % 128 == 0 && d0.cout_pad >= d0.cout, "weight must be MFMA-packed");
   FCVSR_CHECK_ARG(!(d0.act == FCVSR_ACT_PRELU) || d0.slope_ptr != nullptr, "PReLU needs slope_ptr");
-  FCVSR_CHECK_ARG(!d0.pixel_shuffle || d0.cout % 4 == 0, "pixel_shuffle needs cout%4==0");
+  FCVSR_CHECK_ARG(!d0.pixel_shuffle || d0.cout % 16 == 0, "pixel_shuffle needs cout%16==0 (sub-pixel-major packing)");
   MfmaArgs a;
+  a.src16 = d0.src[0].dtype != FCVSR_F32;
+  a.dst16 = d0.dst.dtype != FCVSR_F32;
   a.n_groups = n_groups;
   a.n_src = d0.n_src;
   a.n_res = d0.n_res;
@@ -406,6 +472,14 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
     const char* dbg = getenv("FCVSR_MFMA_DBG");
     a.dbg = dbg ? atoi(dbg) : 0;
   }
+  // tile rows per workgroup: 8 (2 per wave) or 4 (1 per wave: half the LDS -> more co-resident workgroups in
+  // different phases).  FCVSR_MFMA_MW overrides for experiments.
+  int mw = d0.kh == 3 ? 1 : 2;   // measured: 3x3 +20..35 % with 4-row tiles, 1x1 (flat) prefers 8 rows
+  {
+    const char* e = getenv("FCVSR_MFMA_MW");
+    if (e) mw = atoi(e) == 1 ? 1 : 2;
+  }
+  const int kTH = 4 * mw;
   int tiles = 0;
   for (int g = 0; g < n_groups; ++g) {
     const fcvsr_conv_desc& d = descs[g];
@@ -416,7 +490,8 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
     FCVSR_CHECK_ARG(d.B > 0 && d.H > 0 && d.W > 0, "empty problem");
     MGroup& G = a.g[g];
     for (int s = 0; s < d.n_src; ++s) {
-      FCVSR_CHECK_ARG(src_ok(d.src[s]) && d.src[s].c == d0.src[s].c, "src: f32, channel-contiguous, 16-byte aligned, c%4==0");
+      FCVSR_CHECK_ARG(src_ok(d.src[s], mma_dtype) && d.src[s].c == d0.src[s].c && d.src[s].dtype == d0.src[0].dtype,
+                      "src: f32 or MFMA dtype (all alike), channel-contiguous, 16-byte aligned, c%4==0 (f32) / c%8==0 (16-bit)");
       G.src[s] = to_view(d.src[s]);
       if (a.flat)
         FCVSR_CHECK_ARG(d.src[s].sy == d.src[s].sx * d.W && d.src[s].sb == d.src[s].sy * d.H, "1x1 needs uniformly strided pixels");
@@ -427,7 +502,8 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
       if (a.flat)
         FCVSR_CHECK_ARG(d.res[q].sy == d.res[q].sx * d.W && d.res[q].sb == d.res[q].sy * d.H, "1x1 needs uniformly strided res");
     }
-    FCVSR_CHECK_ARG(d.dst.ptr && d.dst.dtype == FCVSR_F32 && vec_view_ok(d.dst), "dst must be f32, 16-byte aligned");
+    FCVSR_CHECK_ARG(d.dst.ptr && (d.dst.dtype == FCVSR_F32 || d.dst.dtype == mma_dtype) && d.dst.dtype == d0.dst.dtype &&
+                        vec_view_ok(d.dst), "dst must be f32 or the MFMA dtype, vector-aligned");
     FCVSR_CHECK_ARG(d.bias == nullptr || ((uintptr_t)d.bias % 16) == 0, "bias must be 16-byte aligned");
     G.dst = to_view(d.dst);
     if (a.flat && !d.pixel_shuffle)
@@ -445,7 +521,7 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   }
   for (int g = n_groups; g < 3; ++g) a.g[g] = a.g[0];
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = (mma_dtype == FCVSR_BF16) ? dispatch<true>(a, nt, d0.kh, tiles, st) : dispatch<false>(a, nt, d0.kh, tiles, st);
+  hipError_t e = (mma_dtype == FCVSR_BF16) ? dispatch<true>(a, nt, d0.kh, mw, tiles, st) : dispatch<false>(a, nt, d0.kh, mw, tiles, st);
   if (e != hipSuccess) {
     set_error("fcvsr_conv2d_mfma: launch failed: %s", hipGetErrorString(e));
     return (int)e;

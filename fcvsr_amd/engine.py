@@ -100,14 +100,27 @@ class Engine:
             return wp, None
         return w, (b.detach() if b is not None else None)
 
-    def _weights(self, name, kind):
-        """kind: 'direct' (f32 [taps][cin][cout16]) | torch.bfloat16 | torch.float16 (MFMA layout)."""
-        key = (name, kind)
+    def _weights(self, name, kind, ps=False):
+        """kind: 'direct' (f32 [taps][cin][cout16]) | torch.bfloat16 | torch.float16 (MFMA layout; with ps=True the rows
+        are in the sub-pixel-major order the MFMA kernel's pixel-shuffle epilogue expects)."""
+        key = (name, kind, ps)
         if key not in self._packed:
             w, b = self._logical_weight(name)
-            pk = hip.pack_conv_weight(w) if kind == "direct" else hip.pack_conv_weight_mfma(w, kind)
+            if kind == "direct":
+                pk = hip.pack_conv_weight(w)
+            else:
+                pk = hip.pack_conv_weight_mfma(w, kind, ps=ps)
+                if ps and b is not None:
+                    b = b[hip.ps_order(w.shape[0]).to(b.device)].contiguous()
             self._packed[key] = (pk, b, w.shape[0], w.shape[-1])
         return self._packed[key]
+
+    def _adt(self, freq=False):
+        """Storage dtype for tensors whose only consumers are MFMA convolutions: the MFMA operand dtype itself
+        (the consumer would round to it anyway, so results are bit-identical and the HBM bytes halve)."""
+        if self.precision == "f32":
+            return torch.float32
+        return torch.bfloat16 if (self.precision == "bf16" or freq) else torch.float16
 
     def _mask(self, Q, H, W, dev):
         key = (Q, H, W, str(dev))
@@ -127,10 +140,14 @@ class Engine:
         """One conv layer applied to 1..3 tensors that share its weights (pyramid levels): a single grouped MFMA launch in
         the 16-bit modes, per-tensor exact-f32 direct launches otherwise."""
         ksz = self._par[name + ".weight"].shape[-1]
-        if self.precision != "f32" and not direct and hip.mfma_eligible(ksz, stride, groups):
+        any16 = any(t.dtype != torch.float32 for g in groups for t in list(g["srcs"]) + [g["dst"]])
+        elig = self.precision != "f32" and not direct and hip.mfma_eligible(ksz, stride, groups)
+        if any16 and not elig:
+            raise RuntimeError(f"{name}: 16-bit activations require the MFMA path (ineligible shape/alignment)")
+        if elig:
             # spectra are unnormalised (|DC| ~ H*W*mean can exceed the f16 range): frequency-domain layers use bf16
             dt = torch.bfloat16 if (self.precision == "bf16" or freq) else torch.float16
-            w, b, cout, _ = self._weights(name, dt)
+            w, b, cout, _ = self._weights(name, dt, ps)
             hip.conv2d_mfma(groups, w, ksz, cout, hip.BF16 if dt == torch.bfloat16 else hip.F16, bias=b, act=act,
                             slope=slope, slope_t=slope_t, res_scale=res_scale, pixel_shuffle=ps)
             return
@@ -144,8 +161,8 @@ class Engine:
             self.taps[name] = t_nhwc.permute(0, 3, 1, 2).contiguous().clone()
 
     @staticmethod
-    def _new(dev, *shape):
-        return torch.empty(*shape, device=dev, dtype=torch.float32)
+    def _new(dev, *shape, dtype=torch.float32):
+        return torch.empty(*shape, device=dev, dtype=dtype)
 
     def _channel_sum(self, t):
         B, H, W, Cc = t.shape
@@ -186,13 +203,14 @@ class Engine:
 
         # offset spectra: (x?f - x2f) + convfuse(cat[x?f, x2f]); batch index = dir*B + b
         off = self._new(dev, 2 * B, H, Wf, 2 * n)
-        t0 = self._new(dev, B, H, Wf, 2 * n)
-        t1 = self._new(dev, B, H, Wf, 2 * n)
+        fdt = self._adt(freq=True)
+        t0 = self._new(dev, B, H, Wf, 2 * n, dtype=fdt)
+        t1 = self._new(dev, B, H, Wf, 2 * n, dtype=fdt)
         for d, xa in enumerate((x1f, x3f)):
             self._conv("MGAA.convfuse.0", [xa, x2f], t0, act=ACT_RELU, freq=True)
             self._conv("MGAA.convfuse.2", [t0], t1, act=ACT_RELU, freq=True)
             self._conv("MGAA.convfuse.4", [t1], off[d * B:(d + 1) * B], res=[xa, x2f], res_scale=[1.0, -1.0], freq=True)
-        s0 = self._new(dev, B, H, Wf, n)
+        s0 = self._new(dev, B, H, Wf, n, dtype=fdt)
         sim = self._new(dev, B, H, Wf, 4)
         self._conv("MGAA.convcrt.0", [x2f], s0, act=ACT_RELU, freq=True)
         self._conv("MGAA.convcrt.2", [s0], sim, freq=True)
@@ -201,8 +219,8 @@ class Engine:
         cv = view(corr)
         check(L.fcvsr_corr_lookup(x1f.data_ptr(), x2f.data_ptr(), 6 * n, B, H, Wf, 2 * n, 4, C.byref(cv), st),
               "fcvsr_corr_lookup")
-        c0 = self._new(dev, 2 * B, H, Wf, n)
-        c1 = self._new(dev, 2 * B, H, Wf, n)
+        c0 = self._new(dev, 2 * B, H, Wf, n, dtype=fdt)
+        c1 = self._new(dev, 2 * B, H, Wf, n, dtype=fdt)
         off4 = self._new(dev, 2 * B, H, Wf, 4)
         for d in range(2):
             self._conv("MGAA.convcorr.0", [off[d * B:(d + 1) * B], corr], c0[d * B:(d + 1) * B], act=ACT_RELU, freq=True)
@@ -226,8 +244,8 @@ class Engine:
               "fcvsr_irfft2")
 
         # kernel predictor (only the F1 half of F[1] is ever read)
-        kp = self._new(dev, B, H, W, n)
-        k0 = self._new(dev, B, H, W, n)
+        kp = self._new(dev, B, H, W, n, dtype=self._adt())
+        k0 = self._new(dev, B, H, W, n, dtype=self._adt())
         K = self._new(dev, B, H, W, A * 3 * n)
         self._conv("MGAA.conv_KP", [x2], kp)
         self._conv("MGAA.F.0", [kp], k0)
@@ -324,13 +342,13 @@ class Engine:
         L = lib()
         st = stream_ptr()
         par = self._par
-        def like(x, c):
-            return self._new(x.device, x.shape[0], x.shape[1], x.shape[2], c)
+        def like(x, c, dtype=torch.float32):
+            return self._new(x.device, x.shape[0], x.shape[1], x.shape[2], c, dtype=dtype)
 
         # the four 3x3 convs of the block run once per layer over all three pyramid levels (shared weights, one launch)
-        t1 = [like(x, 2 * n) for x in xs]
+        t1 = [like(x, 2 * n, self._adt()) for x in xs]      # consumed only by the next conv -> MFMA operand dtype
         t2 = [like(x, n) for x in xs]
-        r1 = [like(x, n) for x in xs]
+        r1 = [like(x, n, self._adt()) for x in xs]
         rr = [like(x, n) for x in xs]
         self._convg(pre + ".body.0", [dict(srcs=[x], dst=t) for x, t in zip(xs, t1)], act=ACT_LEAKY, slope=0.1)
         self._convg(pre + ".body.2", [dict(srcs=[a], dst=t) for a, t in zip(t1, t2)])
@@ -441,16 +459,16 @@ class Engine:
         self._conv("upconv1_L2", [o1], l2, act=ACT_PRELU, slope_t=a_t)
         l2p = self._new(dev, B, H, W, n // 4)
         self._conv("upconv1_L2_2", [l2, l3_1], l2p, res=[l2], ps=True)
-        fz0 = self._new(dev, B, H, W, n)
+        fz0 = self._new(dev, B, H, W, n, dtype=self._adt())
         fz = self._new(dev, B, H, W, n)
         self._conv("upconv_fuse", [o0, l2p, l3_2], fz0)
         self._conv("recorb0", [fz0], fz)
         self._tap("fz", fz)
 
         # up-sampler (:2641-2645)
-        u1 = self._new(dev, B, 2 * H, 2 * W, n)
+        u1 = self._new(dev, B, 2 * H, 2 * W, n, dtype=self._adt())
         self._conv("upconv1", [fz], u1, act=ACT_PRELU, slope_t=a_t, ps=True)
-        u2 = self._new(dev, B, 4 * H, 4 * W, n)
+        u2 = self._new(dev, B, 4 * H, 4 * W, n, dtype=self._adt())
         self._conv("upconv2", [u1], u2, act=ACT_PRELU, slope_t=a_t, ps=True)
         out = self._new(dev, B, Cimg, 4 * H, 4 * W)               # NCHW boundary tensor
         out_v = out.permute(0, 2, 3, 1)

@@ -121,8 +121,16 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     return out.contiguous()
 
 
-def pack_conv_weight_mfma(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+def ps_order(cout: int) -> torch.Tensor:
+    """Row permutation for pixel-shuffled MFMA layers: new row (2i+j)*(cout/4)+c <- original channel 4c+2i+j."""
+    q = cout // 4
+    return torch.tensor([4 * c + sp for sp in range(4) for c in range(q)], dtype=torch.long)
+
+
+def pack_conv_weight_mfma(w: torch.Tensor, dtype: torch.dtype, ps: bool = False) -> torch.Tensor:
     """(Cout, Cin, kh, kw) -> 16-bit [kh*kw][ceil128(Cout)][ceil64(Cin)], zero padded (layout of fcvsr_conv2d_mfma)."""
+    if ps:
+        w = w[ps_order(w.shape[0]).to(w.device)]
     cout, cin, kh, kw = w.shape
     cop, cip = (cout + 127) // 128 * 128, (cin + 63) // 64 * 64
     out = torch.zeros(kh * kw, cop, cip, dtype=dtype, device=w.device)
@@ -162,7 +170,8 @@ def mfma_eligible(ksize: int, stride: int, groups) -> bool:
     for g in groups:
         for s in g["srcs"]:
             sb, sy, sx, sc = s.stride()
-            if s.dtype != torch.float32 or sc != 1 or s.shape[3] % 4 or sx % 4 or sy % 4 or sb % 4 or s.data_ptr() % 16:
+            gran = 4 if s.dtype == torch.float32 else 8
+            if sc != 1 or s.shape[3] % gran or sx % gran or sy % gran or sb % gran or s.data_ptr() % 16:
                 return False
             if ksize == 1 and (sy != sx * s.shape[2] or (s.shape[0] > 1 and sb != sy * s.shape[1])):
                 return False

@@ -77,7 +77,11 @@ int fcvsr_conv2d(const fcvsr_conv_desc* d, void* stream);
  * to `mma_dtype` (FCVSR_BF16 | FCVSR_F16) while staging through LDS, f32 accumulate and f32 epilogue.
  * `descs[0..n_groups)` (1..3) are problems that share weights/epilogue but have their own tensors and sizes (the three
  * pyramid levels of BlockRCB, CVSR_freq.py:766-777) and run in ONE launch.
- * weight: 16-bit [kh*kw][cout_pad][cin_pad], cout_pad = ceil128(cout), cin_pad = ceil64(cin), zero padded. */
+ * weight: 16-bit [kh*kw][cout_pad][cin_pad], cout_pad = ceil128(cout), cin_pad = ceil64(cin), zero padded.
+ * src views may be f32 or already `mma_dtype` (all alike); dst may be f32 or `mma_dtype` (16-bit storage for tensors whose
+ * only consumers are further MFMA convolutions: bit-identical results, half the HBM bytes); res views are f32.
+ * With pixel_shuffle the weight/bias rows must be ordered sub-pixel-major: row (2*i+j)*(cout/4)+c holds original output
+ * channel 4*c+2*i+j, so that one lane's 4 consecutive couts land in one pixel of the shuffled output. */
 int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int mma_dtype, void* stream);
 
 /* ---- frequency transforms: torch.fft.rfft2 / irfft2 (norm='backward') of NHWC channel groups -------------

@@ -32,6 +32,17 @@ def run(name, B, levels, cin, cout, k, iters=30):
 
 
 L3 = [(180, 320), (90, 160), (45, 80)]
+if os.environ.get("MWTEST"):
+    for mw in ("2", "1"):
+        os.environ["FCVSR_MFMA_MW"] = mw
+        print("MW", mw)
+        for B in (1, 4):
+            run("3x3 64->128 L0+L1+L2", B, L3, 64, 128, 3)
+            run("3x3 128->64 L0+L1+L2", B, L3, 128, 64, 3)
+            run("3x3 64->64 L0+L1+L2", B, L3, 64, 64, 3)
+            run("1x1 64->576 L0", B, L3[:1], 64, 576, 1)
+            run("1x1 256->128 freq(180x161)", B, [(180, 161)], 256, 128, 1)
+    sys.exit(0)
 if os.environ.get("ABLATE"):
     for dbg in (0, 1, 2, 4, 3, 5, 6, 7):
         os.environ["FCVSR_MFMA_DBG"] = str(dbg)

@@ -59,10 +59,33 @@ def test_conv_mfma_vs_torch(dt, cins, cout, k, ps):
         dst = torch.empty(B, H, W, cout, device="cuda")
     g = dict(srcs=[nhwc(x) for x in xs], dst=dst, res=[nhwc(res)])
     assert hip.mfma_eligible(k, 1, [g])
-    hip.conv2d_mfma([g], hip.pack_conv_weight_mfma(w.cuda(), tdt), k, cout, hip.BF16 if dt == "bf16" else hip.F16,
-                    bias=b.cuda(), act=hip.ACT_LEAKY, slope=0.2, res_scale=[0.5], pixel_shuffle=ps)
+    bd = b.cuda()
+    if ps:      # pixel-shuffled layers use sub-pixel-major row order for weights and bias (residuals stay natural)
+        bd = bd[hip.ps_order(cout).cuda()].contiguous()
+    hip.conv2d_mfma([g], hip.pack_conv_weight_mfma(w.cuda(), tdt, ps=ps), k, cout, hip.BF16 if dt == "bf16" else hip.F16,
+                    bias=bd, act=hip.ACT_LEAKY, slope=0.2, res_scale=[0.5], pixel_shuffle=ps)
     err = float((nchw(dst) - ref).abs().max())
     assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_conv_mfma_16bit_storage_is_bit_identical(dt):
+    """A 16-bit intermediate between two MFMA convs gives exactly the result of an f32 intermediate (the consumer rounds
+    its input to the MFMA dtype anyway)."""
+    from fcvsr_amd import hip
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    mdt = hip.BF16 if dt == "bf16" else hip.F16
+    x = nhwc(_rand(2, 64, 24, 40))
+    w1 = hip.pack_conv_weight_mfma((_rand(128, 64, 3, 3, seed=1) / 24).cuda(), tdt)
+    w2 = hip.pack_conv_weight_mfma((_rand(64, 128, 3, 3, seed=2) / 34).cuda(), tdt)
+    outs = []
+    for mid_dt in (torch.float32, tdt):
+        mid = torch.empty(2, 24, 40, 128, device="cuda", dtype=mid_dt)
+        out = torch.empty(2, 24, 40, 64, device="cuda")
+        hip.conv2d_mfma([dict(srcs=[x], dst=mid)], w1, 3, 128, mdt, act=hip.ACT_LEAKY, slope=0.1)
+        hip.conv2d_mfma([dict(srcs=[mid], dst=out)], w2, 3, 64, mdt)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_conv_mfma_grouped_levels():

@@ -129,9 +129,9 @@ def main():
         hip.PROFILE = None
         kind = "direct" if args.precision == "f32" else "mfma"
         dom = [r for r in recs if r[3] == kind]
-        tot_ms = sum(a.elapsed_time(b) for a, b, _, _ in dom)
-        tot_fl = sum(f for _, _, f, _ in dom)
-        all_fl = sum(f for _, _, f, _ in recs)
+        tot_ms = sum(r[0].elapsed_time(r[1]) for r in dom)
+        tot_fl = sum(r[2] for r in dom)
+        all_fl = sum(r[2] for r in recs)
         peak = PEAK_TFLOPS[args.precision]
         ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         roofline = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",

@@ -166,7 +166,7 @@ __device__ __forceinline__ void epilogue_quad(const EpiCtx& e, float4 v, const f
 }
 
 template <bool BF16, int NT, int KS, int MW>
-__global__ __launch_bounds__(256, MW == 1 ? 4 : 2) void conv_mfma_kernel(MfmaArgs a) {
+__global__ __launch_bounds__(256, MW == 1 ? (NT == 128 ? 3 : 4) : 2) void conv_mfma_kernel(MfmaArgs a) {
   constexpr int kTH = 4 * MW;                       // MW tile rows (M-fragments) per wave
   constexpr int PAD = KS / 2;
   constexpr int HH = kTH + 2 * PAD, HWD = kTW + 2 * PAD;
@@ -474,7 +474,7 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   }
   // tile rows per workgroup: 8 (2 per wave) or 4 (1 per wave: half the LDS -> more co-resident workgroups in
   // different phases).  FCVSR_MFMA_MW overrides for experiments.
-  int mw = d0.kh == 3 ? 1 : 2;   // measured: 3x3 +20..35 % with 4-row tiles, 1x1 (flat) prefers 8 rows
+  int mw = 1;   // measured: 4-row tiles (more co-resident workgroups in different phases) win for 3x3 and 1x1 alike
   {
     const char* e = getenv("FCVSR_MFMA_MW");
     if (e) mw = atoi(e) == 1 ? 1 : 2;

@@ -1,0 +1,168 @@
+// Fused IAC step (reference CVSR_freq.py:1230-1250, one loop iteration):
+//     out = LeakyReLU_0.1( SAC_h( SAC_v( flow_warp(prev, off), K1 ), K1 ) + feat_in )
+// i.e. bilinear warp (:1188-1227), vertical 3-tap adaptive conv, horizontal 3-tap adaptive conv with kernel1 again (:1273),
+// residual and activation - one kernel instead of three, the warped tile `s` and the vertical result `v` never leave LDS.
+//
+// Workgroup = 4 x 16 output pixels x 32 channels.  Phase 1 warps the (4+2) x (16+2) halo tile (replicate padding = clamped
+// coordinates) into LDS, phase 2 produces v on 4 x (16+2), phase 3 the output.  Lanes run over (pixel, channel quad): the 8
+// quads of a pixel are 8 consecutive lanes, so feature accesses are 128-byte runs and the per-pixel adaptive kernels
+// (12 values per quad, channel index c*3+t) are 192/384-byte runs.  HBM-bound: the dominant traffic is K1
+// (3*C values per pixel per step), read once from HBM (second touch hits L2) in f32 or the 16-bit MFMA dtype.
+#include "common.h"
+
+namespace fcvsr {
+
+constexpr int kIY = 4, kIX = 16, kIC = 32;            // tile rows, cols, channels per workgroup
+constexpr int kIHX = kIX + 2, kIHY = kIY + 2;
+
+template <int KDT>
+__device__ __forceinline__ void load_k12(const void* base, long long elem_off, float k[4][3]) {
+  if (KDT == FCVSR_F32) {
+    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem_off);
+    const float4 a = p[0], b = p[1], c = p[2];
+    k[0][0] = a.x; k[0][1] = a.y; k[0][2] = a.z; k[1][0] = a.w; k[1][1] = b.x; k[1][2] = b.y;
+    k[2][0] = b.z; k[2][1] = b.w; k[2][2] = c.x; k[3][0] = c.y; k[3][1] = c.z; k[3][2] = c.w;
+  } else {
+    const uint2* p = reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem_off);
+    const uint2 a = p[0], b = p[1], c = p[2];
+    const unsigned w[6] = {a.x, a.y, b.x, b.y, c.x, c.y};
+    float f[12];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (KDT == FCVSR_BF16) {
+        f[2 * i] = __uint_as_float(w[i] << 16);
+        f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+      } else {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        const h2 hv = __builtin_bit_cast(h2, w[i]);
+        f[2 * i] = (float)hv[0];
+        f[2 * i + 1] = (float)hv[1];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) k[c][t] = f[c * 3 + t];
+  }
+}
+
+template <int KDT>
+__global__ __launch_bounds__(256) void iac_step_kernel(View prev, View off, View k1, View fin, float slope, int B, int H,
+                                                       int W, View dst, int tiles_x, int tiles_y) {
+  __shared__ __align__(16) float s_s[kIHY * kIHX * kIC];
+  __shared__ __align__(16) float v_s[kIY * kIHX * kIC];
+  const int tid = threadIdx.x;
+  const int quad = tid & 7;
+  const int c0 = blockIdx.y * kIC + quad * 4;
+  const int t = blockIdx.x;
+  const int b = t / (tiles_x * tiles_y);
+  const int t2 = t - b * tiles_x * tiles_y;
+  const int ty0 = (t2 / tiles_x) * kIY, tx0 = (t2 % tiles_x) * kIX;
+
+  // ---- phase 1: s = flow_warp(prev, off) on the halo tile (coordinates clamped = replicate padding of s) -------------
+  const float* pp = prev.p + (long long)b * prev.sb + c0;
+  for (int hp = tid >> 3; hp < kIHY * kIHX; hp += 32) {
+    const int hy = hp / kIHX, hx = hp - hy * kIHX;
+    int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+    gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
+    gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
+    const float* op = off.p + (long long)b * off.sb + (long long)gy * off.sy + (long long)gx * off.sx;
+    const float fx = (float)gx + op[0];
+    const float fy = (float)gy + op[off.sc];
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float wx1 = fx - x0f, wy1 = fy - y0f;
+    const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const bool sane = (fx > -2.f) && (fx < (float)W + 1.f) && (fy > -2.f) && (fy < (float)H + 1.f);
+    const int x0 = sane ? (int)x0f : -4, y0 = sane ? (int)y0f : -4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int xi = x0 + dx, yi = y0 + dy;
+        if (xi >= 0 && xi < W && yi >= 0 && yi < H) {
+          const float w = (dy ? wy1 : wy0) * (dx ? wx1 : wx0);
+          const float4 v = *reinterpret_cast<const float4*>(pp + (long long)yi * prev.sy + (long long)xi * prev.sx);
+          acc.x = fmaf(v.x, w, acc.x); acc.y = fmaf(v.y, w, acc.y);
+          acc.z = fmaf(v.z, w, acc.z); acc.w = fmaf(v.w, w, acc.w);
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(s_s + hp * kIC + quad * 4) = acc;
+  }
+  __syncthreads();
+
+  // ---- phase 2: v[y][hx] = sum_t s[y+t][hx] * K1[y][clamp(hx)][c*3+t] ---------------------------------------------------
+  for (int vp = tid >> 3; vp < kIY * kIHX; vp += 32) {
+    const int y = vp / kIHX, hx = vp - y * kIHX;
+    int gy = ty0 + y, gx = tx0 + hx - 1;
+    gy = gy > H - 1 ? H - 1 : gy;
+    gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
+    float k[4][3];
+    load_k12<KDT>(k1.p, (long long)b * k1.sb + (long long)gy * k1.sy + (long long)gx * k1.sx + c0 * 3, k);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) {
+      const float4 v = *reinterpret_cast<const float4*>(s_s + ((y + tt) * kIHX + hx) * kIC + quad * 4);
+      acc.x = fmaf(v.x, k[0][tt], acc.x); acc.y = fmaf(v.y, k[1][tt], acc.y);
+      acc.z = fmaf(v.z, k[2][tt], acc.z); acc.w = fmaf(v.w, k[3][tt], acc.w);
+    }
+    *reinterpret_cast<float4*>(v_s + vp * kIC + quad * 4) = acc;
+  }
+  __syncthreads();
+
+  // ---- phase 3: out = lrelu( sum_t v[y][x+t] * K1[y][x][c*3+t] + feat_in ) ------------------------------------------------
+  for (int p = tid >> 3; p < kIY * kIX; p += 32) {
+    const int y = p / kIX, x = p - y * kIX;
+    const int gy = ty0 + y, gx = tx0 + x;
+    if (gy < H && gx < W) {
+      float k[4][3];
+      load_k12<KDT>(k1.p, (long long)b * k1.sb + (long long)gy * k1.sy + (long long)gx * k1.sx + c0 * 3, k);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt) {
+        const float4 v = *reinterpret_cast<const float4*>(v_s + (y * kIHX + x + tt) * kIC + quad * 4);
+        acc.x = fmaf(v.x, k[0][tt], acc.x); acc.y = fmaf(v.y, k[1][tt], acc.y);
+        acc.z = fmaf(v.z, k[2][tt], acc.z); acc.w = fmaf(v.w, k[3][tt], acc.w);
+      }
+      const float4 f = *reinterpret_cast<const float4*>(fin.p + (long long)b * fin.sb + (long long)gy * fin.sy +
+                                                        (long long)gx * fin.sx + c0);
+      acc.x += f.x; acc.y += f.y; acc.z += f.z; acc.w += f.w;
+      acc.x = acc.x >= 0.f ? acc.x : acc.x * slope; acc.y = acc.y >= 0.f ? acc.y : acc.y * slope;
+      acc.z = acc.z >= 0.f ? acc.z : acc.z * slope; acc.w = acc.w >= 0.f ? acc.w : acc.w * slope;
+      *reinterpret_cast<float4*>(dst.p + (long long)b * dst.sb + (long long)gy * dst.sy + (long long)gx * dst.sx + c0) = acc;
+    }
+  }
+}
+
+}  // namespace fcvsr
+
+using namespace fcvsr;
+
+static bool quad_ok(const fcvsr_view* v) { return v && v->ptr && v->dtype == FCVSR_F32 && vec4_ok(*v); }
+
+extern "C" int fcvsr_iac_step(const fcvsr_view* prev, const fcvsr_view* off, const fcvsr_view* k1, const fcvsr_view* feat_in,
+                              float slope, int B, int H, int W, const fcvsr_view* dst, void* stream) {
+  FCVSR_CHECK_ARG(quad_ok(prev) && quad_ok(feat_in) && quad_ok(dst), "prev/feat_in/dst: f32, channel-contiguous, aligned");
+  FCVSR_CHECK_ARG(off && off->ptr && off->c >= 2 && off->dtype == FCVSR_F32, "off needs 2 f32 channels");
+  FCVSR_CHECK_ARG(k1 && k1->ptr && k1->sc == 1 && k1->c == 3 * prev->c, "k1 must have 3*C contiguous channels");
+  FCVSR_CHECK_ARG(prev->c % kIC == 0 && prev->c == dst->c && prev->c == feat_in->c, "C must be a multiple of 32");
+  FCVSR_CHECK_ARG(B > 0 && H > 0 && W > 0, "bad sizes");
+  const int g = k1->dtype == FCVSR_F32 ? 4 : 8;   // 16-byte (f32) / 8-byte (16-bit) vector loads of 12-element groups
+  FCVSR_CHECK_ARG(((uintptr_t)k1->ptr % 16) == 0 && k1->sx % g == 0 && k1->sy % g == 0 && k1->sb % g == 0, "k1 alignment");
+  const int tx = cdiv(W, kIX), ty = cdiv(H, kIY);
+  dim3 grid(B * tx * ty, prev->c / kIC);
+  hipStream_t st = (hipStream_t)stream;
+  View kv = to_view(*k1);
+  if (k1->dtype == FCVSR_F32)
+    hipLaunchKernelGGL((iac_step_kernel<FCVSR_F32>), grid, dim3(256), 0, st, to_view(*prev), to_view(*off), kv,
+                       to_view(*feat_in), slope, B, H, W, to_view(*dst), tx, ty);
+  else if (k1->dtype == FCVSR_BF16)
+    hipLaunchKernelGGL((iac_step_kernel<FCVSR_BF16>), grid, dim3(256), 0, st, to_view(*prev), to_view(*off), kv,
+                       to_view(*feat_in), slope, B, H, W, to_view(*dst), tx, ty);
+  else
+    hipLaunchKernelGGL((iac_step_kernel<FCVSR_F16>), grid, dim3(256), 0, st, to_view(*prev), to_view(*off), kv,
+                       to_view(*feat_in), slope, B, H, W, to_view(*dst), tx, ty);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}

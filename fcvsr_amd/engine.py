@@ -149,12 +149,12 @@ class Engine:
             dt = torch.bfloat16 if (self.precision == "bf16" or freq) else torch.float16
             w, b, cout, _ = self._weights(name, dt, ps)
             hip.conv2d_mfma(groups, w, ksz, cout, hip.BF16 if dt == torch.bfloat16 else hip.F16, bias=b, act=act,
-                            slope=slope, slope_t=slope_t, res_scale=res_scale, pixel_shuffle=ps)
+                            slope=slope, slope_t=slope_t, res_scale=res_scale, pixel_shuffle=ps, name=name)
             return
         w, b, cout, _ = self._weights(name, "direct")
         for g in groups:
             hip.conv2d(g["srcs"], w, ksz, cout, g["dst"], bias=b, stride=stride, act=act, slope=slope, slope_t=slope_t,
-                       res=g.get("res", ()), res_scale=res_scale, pixel_shuffle=ps)
+                       res=g.get("res", ()), res_scale=res_scale, pixel_shuffle=ps, name=name)
 
     def _tap(self, name, t_nhwc):
         if self.taps is not None:
@@ -246,16 +246,19 @@ class Engine:
         # kernel predictor (only the F1 half of F[1] is ever read)
         kp = self._new(dev, B, H, W, n, dtype=self._adt())
         k0 = self._new(dev, B, H, W, n, dtype=self._adt())
-        K = self._new(dev, B, H, W, A * 3 * n)
+        # the adaptive kernels feed only the IAC kernel: in the 16-bit modes they are stored in the MFMA dtype
+        fused_iac = n % 32 == 0                       # fused kernel works on 32-channel slabs; else 3-kernel f32 path
+        K = self._new(dev, B, H, W, A * 3 * n, dtype=self._adt() if fused_iac else torch.float32)
         self._conv("MGAA.conv_KP", [x2], kp)
         self._conv("MGAA.F.0", [kp], k0)
         self._conv("MGAA.F.1", [k0], K)
 
         # iterative alignment: warp -> SAC(kernel1 twice) -> + feat_in -> LeakyReLU(0.1)
         al = self._new(dev, B, H, W, 2 * n)
-        s = self._new(dev, B, H, W, n)
-        vbuf = self._new(dev, B, H, W, n)
         ping = [self._new(dev, B, H, W, n), self._new(dev, B, H, W, n)]
+        if not fused_iac:
+            s = self._new(dev, B, H, W, n)
+            vbuf = self._new(dev, B, H, W, n)
         for d, fin in enumerate((x1, x3)):
             cur = fin
             fv = view(fin)
@@ -264,11 +267,16 @@ class Engine:
                 o_v = view(offsets[..., 2 * g:2 * g + 2])
                 k_v = view(K[..., i * 3 * n:(i + 1) * 3 * n])
                 dst = al[..., d * n:(d + 1) * n] if i == A - 1 else ping[i % 2]
-                cur_v, s_v, v_v, d_v = view(cur), view(s), view(vbuf), view(dst)
-                check(L.fcvsr_warp(C.byref(cur_v), C.byref(o_v), B, H, W, C.byref(s_v), st), "fcvsr_warp")
-                check(L.fcvsr_sac_v(C.byref(s_v), C.byref(k_v), B, H, W, C.byref(v_v), st), "fcvsr_sac_v")
-                check(L.fcvsr_sac_h(C.byref(v_v), C.byref(k_v), C.byref(fv), 0.1, B, H, W, C.byref(d_v), st),
-                      "fcvsr_sac_h")
+                cur_v, d_v = view(cur), view(dst)
+                if fused_iac:
+                    check(L.fcvsr_iac_step(C.byref(cur_v), C.byref(o_v), C.byref(k_v), C.byref(fv), 0.1, B, H, W,
+                                           C.byref(d_v), st), "fcvsr_iac_step")
+                else:
+                    s_v, v_v = view(s), view(vbuf)
+                    check(L.fcvsr_warp(C.byref(cur_v), C.byref(o_v), B, H, W, C.byref(s_v), st), "fcvsr_warp")
+                    check(L.fcvsr_sac_v(C.byref(s_v), C.byref(k_v), B, H, W, C.byref(v_v), st), "fcvsr_sac_v")
+                    check(L.fcvsr_sac_h(C.byref(v_v), C.byref(k_v), C.byref(fv), 0.1, B, H, W, C.byref(d_v), st),
+                          "fcvsr_sac_h")
                 cur = dst
         out = self._new(dev, B, H, W, n)
         self._conv("MGAA.conv3", [al], out, res=[x2])

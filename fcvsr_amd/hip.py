@@ -64,6 +64,7 @@ SIGNATURES = {
     "fcvsr_warp": [_PV, _PV, _I, _I, _I, _PV, _VP],
     "fcvsr_sac_v": [_PV, _PV, _I, _I, _I, _PV, _VP],
     "fcvsr_sac_h": [_PV, _PV, _PV, _F, _I, _I, _I, _PV, _VP],
+    "fcvsr_iac_step": [_PV, _PV, _PV, _PV, _F, _I, _I, _I, _PV, _VP],
     "fcvsr_divenh": [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _F, _VP, _VP, _VP, _VP, _I64, _I, _I, _I, _I, _VP],
     "fcvsr_scale_add": [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP],
     "fcvsr_gc_context": [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _I64, _VP],
@@ -184,7 +185,8 @@ def mfma_eligible(ksize: int, stride: int, groups) -> bool:
 
 def conv2d_mfma(groups, wpacked: torch.Tensor, ksize: int, cout: int, mma_dtype: int, *,
                 bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, slope: float = 0.0,
-                slope_t: Optional[torch.Tensor] = None, res_scale: Sequence[float] = (), pixel_shuffle: bool = False):
+                slope_t: Optional[torch.Tensor] = None, res_scale: Sequence[float] = (), pixel_shuffle: bool = False,
+                name: str = ""):
     """groups: 1..3 dicts {srcs: [..], dst: t, res: [..]} sharing weights / epilogue (one launch)."""
     n = len(groups)
     descs = (ConvDesc * n)()
@@ -199,7 +201,7 @@ def conv2d_mfma(groups, wpacked: torch.Tensor, ksize: int, cout: int, mma_dtype:
         e0.record()
         check(lib().fcvsr_conv2d_mfma(descs, n, mma_dtype, stream_ptr()), "fcvsr_conv2d_mfma")
         e1.record()
-        PROFILE.append((e0, e1, flops, "mfma"))
+        PROFILE.append((e0, e1, flops, "mfma", name))
         return
     check(lib().fcvsr_conv2d_mfma(descs, n, mma_dtype, stream_ptr()), "fcvsr_conv2d_mfma")
 
@@ -207,7 +209,7 @@ def conv2d_mfma(groups, wpacked: torch.Tensor, ksize: int, cout: int, mma_dtype:
 def conv2d(srcs: Sequence[torch.Tensor], wpacked: torch.Tensor, ksize: int, cout: int, dst: torch.Tensor, *,
            bias: Optional[torch.Tensor] = None, stride: int = 1, act: int = ACT_NONE, slope: float = 0.0,
            slope_t: Optional[torch.Tensor] = None, res: Sequence[torch.Tensor] = (),
-           res_scale: Sequence[float] = (), pixel_shuffle: bool = False) -> torch.Tensor:
+           res_scale: Sequence[float] = (), pixel_shuffle: bool = False, name: str = "") -> torch.Tensor:
     """srcs / res / dst are (b,y,x,c)-ordered tensors (any strides)."""
     d = ConvDesc()
     cin = _fill_desc(d, srcs, wpacked, ksize, cout, wpacked.shape[-1], dst, bias, stride, act, slope, slope_t, res,
@@ -220,7 +222,7 @@ def conv2d(srcs: Sequence[torch.Tensor], wpacked: torch.Tensor, ksize: int, cout
         e1.record()
         ho = (d.H + 2 * d.pad - d.kh) // stride + 1
         wo = (d.W + 2 * d.pad - d.kw) // stride + 1
-        PROFILE.append((e0, e1, 2.0 * d.B * ho * wo * cout * cin * ksize * ksize, "direct"))
+        PROFILE.append((e0, e1, 2.0 * d.B * ho * wo * cout * cin * ksize * ksize, "direct", name))
         return dst
     check(lib().fcvsr_conv2d(C.byref(d), stream_ptr()), "fcvsr_conv2d")
     return dst

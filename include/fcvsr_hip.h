@@ -122,6 +122,11 @@ int fcvsr_sac_v(const fcvsr_view* s, const fcvsr_view* k1, int B, int H, int W, 
 int fcvsr_sac_h(const fcvsr_view* v, const fcvsr_view* k1, const fcvsr_view* feat_in, float slope,
                 int B, int H, int W, const fcvsr_view* dst, void* stream);
 
+/* One fused IAC iteration (:1230-1250): dst = LeakyReLU_slope(SAC_h(SAC_v(flow_warp(prev, off), k1), k1) + feat_in).
+ * k1: the 3*C kernel1 channels of this iteration, f32 or 16-bit (FCVSR_BF16/FCVSR_F16); everything else f32. C % 32 == 0. */
+int fcvsr_iac_step(const fcvsr_view* prev, const fcvsr_view* off, const fcvsr_view* k1, const fcvsr_view* feat_in,
+                   float slope, int B, int H, int W, const fcvsr_view* dst, void* stream);
+
 /* ---- MultiFreq_Refinment pieces (CVSR_freq.py:2104-2133, :2201-2254) ---------------------------------------- */
 /* DivEnh expressions, i==0 (first=1): t=f-mean_f; e1=0.2*a*t*f+b*f.  i>0: t=f-s_f+0.2*s_o; e1 as above;
  * e2=0.2*a*s_o*f+b*f.   mode 0: write per-(b,c) sums of e1,e2 to sums[2][B][C] (two-stage, deterministic);

@@ -169,6 +169,25 @@ def test_corr_warp_sac_vs_oracle():
     assert float((nchw(out) - ref).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("kdt", ["f32", "bf16", "f16"])
+def test_iac_step_fused_vs_oracle(kdt):
+    from fcvsr_amd import hip
+    from oracle import fcvsr_oracle as O
+    L = hip.lib()
+    B, Cc, H, W = 2, 64, 22, 37                      # partial tiles in both directions
+    f, fin = _rand(B, Cc, H, W, seed=3), _rand(B, Cc, H, W, seed=6)
+    off, k1 = _rand(B, 2, H, W, seed=4) * 3.0, _rand(B, 3 * Cc, H, W, seed=5)
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[kdt]
+    k1r = k1.to(tdt).float()                         # the kernel sees K rounded to its storage dtype
+    fd, find, od, kd = nhwc(f), nhwc(fin), nhwc(off), nhwc(k1).to(tdt)
+    out = torch.empty_like(fd)
+    fv, finv, ov, kv, outv = (hip.view(t) for t in (fd, find, od, kd, out))
+    hip.check(L.fcvsr_iac_step(C.byref(fv), C.byref(ov), C.byref(kv), C.byref(finv), 0.1, B, H, W, C.byref(outv),
+                               hip.stream_ptr()), "iac_step")
+    ref = F.leaky_relu(O.sac_kernel1_twice(O.warp_bilinear(f, off), k1r) + fin, 0.1)
+    assert float((nchw(out) - ref).abs().max()) < 2e-4
+
+
 def test_flow_warp_known_answer():
     """The reference test-suite's own known answer for flow_warp (mmedit_train/tests/test_models/test_common/
     test_flow_warp.py:32-46): flow = -1 everywhere == shift by one pixel with zero fill."""

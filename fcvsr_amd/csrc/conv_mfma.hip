@@ -55,6 +55,8 @@ struct MfmaArgs {
   int ps;
   int flat;            // 1x1: treat pixels as a flat list of B*H*W
   int src16, dst16;    // sources / destination stored in the MFMA dtype (16-bit) instead of f32
+  int planar;          // single f32 source with arbitrary channel stride (the NCHW frames of feat_extract), cin <= 64
+  int sub2;            // stride-2 convolution: evaluate at full resolution, keep the even output pixels only
   int dbg;             // ablation switches for profiling builds (FCVSR_MFMA_DBG): 1 skip staging, 2 skip MFMA, 4 skip stores
 };
 
@@ -78,7 +80,7 @@ __device__ __forceinline__ f32x16_t mfma(uint4 a, uint4 b, f32x16_t c) {
 }
 
 struct EpiCtx {
-  int act, n_res, ps, flat, H, W, b, dst16, cq4;   // cq4 = cout/4 (pixel-shuffle: couts are ordered sub-pixel-major)
+  int act, n_res, ps, flat, H, W, b, dst16, sub2, cq4;   // cq4 = cout/4 (pixel-shuffle: couts are ordered sub-pixel-major)
   float slope, rs0, rs1;
   long long npix;
   View res0, res1, dst;
@@ -89,7 +91,12 @@ struct EpiCtx {
 template <bool BF16>
 __device__ __forceinline__ void epilogue_quad(const EpiCtx& e, float4 v, const float* bias, int cout, int n, int py, int px,
                                               long long pflat) {
-  const bool pok = e.flat ? (pflat < e.npix) : ((py < e.H) && (px < e.W));
+  bool pok = e.flat ? (pflat < e.npix) : ((py < e.H) && (px < e.W));
+  if (e.sub2) {                      // stride 2: only even positions exist in the output; res/dst are at half resolution
+    pok = pok && !((py | px) & 1);
+    py >>= 1;
+    px >>= 1;
+  }
   if (!pok || n >= cout) return;
   const bool full = (n + 3 < cout);
   float x[4] = {v.x, v.y, v.z, v.w};
@@ -215,7 +222,22 @@ __global__ __launch_bounds__(256, MW == 1 ? (NT == 128 ? 3 : 4) : 2) void conv_m
     const int ck = (a.cin16 - c0) < kCK ? (a.cin16 - c0) : kCK;       // multiple of 16
     __syncthreads();   // every wave is done reading A_s / B_s of the previous chunk
     // ---- stage the halo tile of channels [c0, c0+64): f32 HBM -> 16-bit LDS -------------------------------------------
-    if (!a.src16) {
+    if (a.planar) {
+      // NCHW boundary input (7 or 21 frame planes): one scalar load per (pixel, channel); channels padded to 16 with zeros
+      constexpr int NHP = HH * HWD;
+      const View sv = G.src[0];
+      const int cpad = a.cin16;                          // 16 or 32
+      for (int idx = tid; idx < NHP * cpad; idx += 256) {
+        const int hp = idx % NHP, c = idx / NHP;         // consecutive lanes = consecutive pixels of one plane (coalesced)
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        const int iy = ty0 + hy - PAD, ix = tx0 + hx - PAD;
+        float v = 0.f;
+        if (c < a.cin_total && iy >= 0 && iy < G.H && ix >= 0 && ix < G.W && !(a.dbg & 1))
+          v = sv.p[(long long)b * sv.sb + (long long)iy * sv.sy + (long long)ix * sv.sx + (long long)c * sv.sc];
+        const uint2 pk = cvt4<BF16>(make_float4(v, 0.f, 0.f, 0.f));
+        A_s[hp * kLD + c] = (uint16_t)(pk.x & 0xffff);
+      }
+    } else if (!a.src16) {
       constexpr int NHP = HH * HWD;                    // halo pixels
       constexpr int ITERS = (NHP * 16 + 255) / 256;    // 16 channel-quads per pixel, 256 threads
       const int q = tid & 15;
@@ -346,7 +368,7 @@ __global__ __launch_bounds__(256, MW == 1 ? (NT == 128 ? 3 : 4) : 2) void conv_m
   EpiCtx e;
   e.act = a.act; e.slope = slope; e.n_res = a.n_res; e.rs0 = a.rs[0]; e.rs1 = a.rs[1]; e.ps = a.ps; e.flat = a.flat;
   e.res0 = G.res[0]; e.res1 = G.res[1]; e.dst = G.dst; e.H = G.H; e.W = G.W; e.b = b; e.npix = npix;
-  e.dst16 = a.dst16; e.cq4 = a.cout >> 2;
+  e.dst16 = a.dst16; e.cq4 = a.cout >> 2; e.sub2 = a.sub2;
   constexpr int EW = NT >= 64 ? 64 : 32;        // couts per pass
   constexpr int EROW = EW + 4;                  // padded row (floats): conflict-free b32 writes and b128 reads
   constexpr int QPR = EW / 4;                   // float4 per pixel row
@@ -435,14 +457,19 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   FCVSR_CHECK_ARG(descs != nullptr && n_groups >= 1 && n_groups <= 3, "1..3 problem groups");
   FCVSR_CHECK_ARG(mma_dtype == FCVSR_BF16 || mma_dtype == FCVSR_F16, "mma_dtype must be BF16 or F16");
   const fcvsr_conv_desc& d0 = descs[0];
-  FCVSR_CHECK_ARG(d0.kh == d0.kw && (d0.kh == 1 || d0.kh == 3) && d0.stride == 1 && d0.pad == d0.kh / 2,
-                  "MFMA path: 1x1 or 3x3, stride 1, same padding");
+  FCVSR_CHECK_ARG(d0.kh == d0.kw && (d0.kh == 1 || d0.kh == 3) && d0.pad == d0.kh / 2 &&
+                      (d0.stride == 1 || (d0.stride == 2 && d0.kh == 3 && !d0.pixel_shuffle)),
+                  "MFMA path: 1x1 or 3x3 stride 1, or 3x3 stride 2, same padding");
   FCVSR_CHECK_ARG(d0.n_src >= 1 && d0.n_src <= 3 && d0.n_res >= 0 && d0.n_res <= 2 && d0.cout > 0, "bad descriptor");
   FCVSR_CHECK_ARG(d0.weight != nullptr && d0.cout_pad % 128 == 0 && d0.cout_pad >= d0.cout, "weight must be MFMA-packed");
   FCVSR_CHECK_ARG(!(d0.act == FCVSR_ACT_PRELU) || d0.slope_ptr != nullptr, "PReLU needs slope_ptr");
   FCVSR_CHECK_ARG(!d0.pixel_shuffle || d0.cout % 16 == 0, "pixel_shuffle needs cout%16==0 (sub-pixel-major packing)");
   MfmaArgs a;
   a.src16 = d0.src[0].dtype != FCVSR_F32;
+  a.sub2 = d0.stride == 2;
+  a.planar = (d0.n_src == 1 && d0.src[0].sc != 1) ? 1 : 0;
+  FCVSR_CHECK_ARG(!a.planar || (d0.src[0].dtype == FCVSR_F32 && d0.src[0].c <= 32 && d0.kh == 3),
+                  "planar (channel-strided) source: one f32 source with <= 32 channels, 3x3");
   a.dst16 = d0.dst.dtype != FCVSR_F32;
   a.n_groups = n_groups;
   a.n_src = d0.n_src;
@@ -483,14 +510,15 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   int tiles = 0;
   for (int g = 0; g < n_groups; ++g) {
     const fcvsr_conv_desc& d = descs[g];
-    FCVSR_CHECK_ARG(d.kh == d0.kh && d.kw == d0.kw && d.stride == 1 && d.n_src == d0.n_src && d.n_res == d0.n_res &&
+    FCVSR_CHECK_ARG(d.kh == d0.kh && d.kw == d0.kw && d.stride == d0.stride && d.n_src == d0.n_src && d.n_res == d0.n_res &&
                         d.cout == d0.cout && d.weight == d0.weight && d.bias == d0.bias && d.act == d0.act &&
                         d.pixel_shuffle == d0.pixel_shuffle,
                     "groups must share weights and epilogue");
     FCVSR_CHECK_ARG(d.B > 0 && d.H > 0 && d.W > 0, "empty problem");
     MGroup& G = a.g[g];
     for (int s = 0; s < d.n_src; ++s) {
-      FCVSR_CHECK_ARG(src_ok(d.src[s], mma_dtype) && d.src[s].c == d0.src[s].c && d.src[s].dtype == d0.src[0].dtype,
+      FCVSR_CHECK_ARG((a.planar ? (d.src[s].ptr != nullptr && d.src[s].sc != 1) : src_ok(d.src[s], mma_dtype)) &&
+                          d.src[s].c == d0.src[s].c && d.src[s].dtype == d0.src[0].dtype,
                       "src: f32 or MFMA dtype (all alike), channel-contiguous, 16-byte aligned, c%4==0 (f32) / c%8==0 (16-bit)");
       G.src[s] = to_view(d.src[s]);
       if (a.flat)

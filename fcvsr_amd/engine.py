@@ -130,13 +130,13 @@ class Engine:
 
     # ---------------------------------------------------------------------------------------------- helpers
     def _conv(self, name, srcs, dst, *, stride=1, act=ACT_NONE, slope=0.0, slope_t=None, res=(), res_scale=(),
-              ps=False, freq=False, direct=False):
+              ps=False, freq=False, direct=False, force_f16=False):
         self._convg(name, [dict(srcs=srcs, dst=dst, res=res, ps=ps)], stride=stride, act=act, slope=slope,
-                    slope_t=slope_t, res_scale=res_scale, ps=ps, freq=freq, direct=direct)
+                    slope_t=slope_t, res_scale=res_scale, ps=ps, freq=freq, direct=direct, force_f16=force_f16)
         return dst
 
     def _convg(self, name, groups, *, stride=1, act=ACT_NONE, slope=0.0, slope_t=None, res_scale=(), ps=False,
-               freq=False, direct=False):
+               freq=False, direct=False, force_f16=False):
         """One conv layer applied to 1..3 tensors that share its weights (pyramid levels): a single grouped MFMA launch in
         the 16-bit modes, per-tensor exact-f32 direct launches otherwise."""
         ksz = self._par[name + ".weight"].shape[-1]
@@ -147,8 +147,10 @@ class Engine:
         if elig:
             # spectra are unnormalised (|DC| ~ H*W*mean can exceed the f16 range): frequency-domain layers use bf16
             dt = torch.bfloat16 if (self.precision == "bf16" or freq) else torch.float16
+            if force_f16:      # image-domain input in [0,1]: f16's 11-bit significand keeps 8-bit pixels exact
+                dt = torch.float16
             w, b, cout, _ = self._weights(name, dt, ps)
-            hip.conv2d_mfma(groups, w, ksz, cout, hip.BF16 if dt == torch.bfloat16 else hip.F16, bias=b, act=act,
+            hip.conv2d_mfma(groups, w, ksz, cout, hip.BF16 if dt == torch.bfloat16 else hip.F16, stride=stride, bias=b, act=act,
                             slope=slope, slope_t=slope_t, res_scale=res_scale, pixel_shuffle=ps, name=name)
             return
         w, b, cout, _ = self._weights(name, "direct")
@@ -443,7 +445,7 @@ class Engine:
         a_t = m.lrelu.weight
         xin = x.view(B, T * Cimg, H, W).permute(0, 2, 3, 1)      # (b,y,x,c) strided view of the NCHW frames
         feat = self._new(dev, B, H, W, 7 * n)
-        self._conv("feat_extract.0", [xin], feat)
+        self._conv("feat_extract.0", [xin], feat, force_f16=True)
         self._tap("feat", feat)
         f1, f2, f3 = feat[..., :3 * n], feat[..., 3 * n:4 * n], feat[..., 4 * n:]
         a1 = self._mgaa(f1[..., :n], f1[..., n:2 * n], f1[..., 2 * n:], "1")

@@ -166,9 +166,14 @@ def _fill_desc(d: "ConvDesc", srcs, wpacked, ksize, cout, cout_pad, dst, bias, s
 
 def mfma_eligible(ksize: int, stride: int, groups) -> bool:
     """Can fcvsr_conv2d_mfma take this problem? (1x1/3x3, stride 1, channel-contiguous 16-byte-aligned f32 inputs)"""
-    if ksize not in (1, 3) or stride != 1:
+    if ksize not in (1, 3) or stride not in (1, 2) or (stride == 2 and ksize != 3):
         return False
     for g in groups:
+        if len(g["srcs"]) == 1 and g["srcs"][0].stride(3) != 1:       # planar (NCHW) source, e.g. feat_extract
+            s0 = g["srcs"][0]
+            if s0.dtype != torch.float32 or s0.shape[3] > 32 or ksize != 3 or stride != 1:
+                return False
+            continue
         for s in g["srcs"]:
             sb, sy, sx, sc = s.stride()
             gran = 4 if s.dtype == torch.float32 else 8
@@ -183,7 +188,7 @@ def mfma_eligible(ksize: int, stride: int, groups) -> bool:
     return True
 
 
-def conv2d_mfma(groups, wpacked: torch.Tensor, ksize: int, cout: int, mma_dtype: int, *,
+def conv2d_mfma(groups, wpacked: torch.Tensor, ksize: int, cout: int, mma_dtype: int, *, stride: int = 1,
                 bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, slope: float = 0.0,
                 slope_t: Optional[torch.Tensor] = None, res_scale: Sequence[float] = (), pixel_shuffle: bool = False,
                 name: str = ""):
@@ -192,10 +197,10 @@ def conv2d_mfma(groups, wpacked: torch.Tensor, ksize: int, cout: int, mma_dtype:
     descs = (ConvDesc * n)()
     flops = 0.0
     for i, g in enumerate(groups):
-        cin = _fill_desc(descs[i], g["srcs"], wpacked, ksize, cout, wpacked.shape[1], g["dst"], bias, 1, act, slope,
+        cin = _fill_desc(descs[i], g["srcs"], wpacked, ksize, cout, wpacked.shape[1], g["dst"], bias, stride, act, slope,
                          slope_t, g.get("res", ()), res_scale, pixel_shuffle)
         assert wpacked.shape[0] == ksize * ksize and wpacked.shape[2] >= cin, (wpacked.shape, ksize, cin)
-        flops += 2.0 * descs[i].B * descs[i].H * descs[i].W * cout * cin * ksize * ksize
+        flops += 2.0 * descs[i].B * descs[i].H * descs[i].W * cout * cin * ksize * ksize / (stride * stride)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -68,6 +68,29 @@ def test_conv_mfma_vs_torch(dt, cins, cout, k, ps):
     assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
 
 
+def test_conv_mfma_stride2_and_planar_source():
+    """rconcat-style stride-2 3x3 (evaluated at full resolution, even pixels kept) and the feat_extract case
+    (7 NCHW frame planes read in place)."""
+    from fcvsr_amd import hip
+    tdt = torch.bfloat16
+    x, w, b = _rand(2, 64, 22, 38), _rand(64, 64, 3, 3, seed=1) / 24, _rand(64, seed=2)
+    ref = F.conv2d(x.to(tdt).float(), w.to(tdt).float(), b, stride=2, padding=1)
+    dst = torch.empty(2, ref.shape[2], ref.shape[3], 64, device="cuda")
+    g = dict(srcs=[nhwc(x)], dst=dst)
+    assert hip.mfma_eligible(3, 2, [g])
+    hip.conv2d_mfma([g], hip.pack_conv_weight_mfma(w.cuda(), tdt), 3, 64, hip.BF16, stride=2, bias=b.cuda())
+    assert float((nchw(dst) - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    # planar NCHW source with 7 channels -> 448
+    x, w, b = torch.rand(2, 7, 20, 44), _rand(448, 7, 3, 3, seed=3) / 8, _rand(448, seed=4)
+    ref = F.conv2d(x.to(tdt).float(), w.to(tdt).float(), b, padding=1)
+    xd = x.cuda()
+    dst = torch.empty(2, 20, 44, 448, device="cuda")
+    g = dict(srcs=[xd.permute(0, 2, 3, 1)], dst=dst)
+    assert hip.mfma_eligible(3, 1, [g])
+    hip.conv2d_mfma([g], hip.pack_conv_weight_mfma(w.cuda(), tdt), 3, 448, hip.BF16, bias=b.cuda())
+    assert float((nchw(dst) - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 def test_conv_mfma_16bit_storage_is_bit_identical(dt):
     """A 16-bit intermediate between two MFMA convs gives exactly the result of an f32 intermediate (the consumer rounds

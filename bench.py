@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1, help="7-frame windows per step per GPU")
+    ap.add_argument("--batch", type=int, default=8, help="7-frame windows per step per GPU (clips are independent)")
     ap.add_argument("--model", choices=["S", "full"], default="S")
     ap.add_argument("--height", type=int, default=180)
     ap.add_argument("--width", type=int, default=320)

@@ -188,8 +188,16 @@ __global__ __launch_bounds__(256, MW == 1 ? (NT == 128 ? 3 : 4) : 2) void conv_m
   const int r = lane & 31, h = lane >> 5;
 
   // ---- which tile ----------------------------------------------------------------------------------------------------
-  const int nb = blockIdx.x % a.n_nblk;
-  const int tflat = blockIdx.x / a.n_nblk;
+  // XCD-aware remap (workgroups are dealt round-robin over the 8 XCDs, each with a private L2): give every XCD one
+  // contiguous run of the work list so that neighbouring tiles - which share halo rows and the N-blocks of a tile,
+  // which share the whole input tile - hit in the same L2.  Bijective for any grid size.
+  int wid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = wid & 7, loc = wid >> 3;
+    wid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  }
+  const int nb = wid % a.n_nblk;
+  const int tflat = wid / a.n_nblk;
   int gi = 0;
   if (a.n_groups > 1 && tflat >= a.g[1].tile_begin) gi = 1;
   if (a.n_groups > 2 && tflat >= a.g[2].tile_begin) gi = 2;

@@ -12,6 +12,7 @@
 //
 // Replaces torch.fft.rfft2 / irfft2 (CVSR_freq.py:1452-1454, :1499, :1504) and the per-channel
 // fftn/fftshift/mask/ifftshift/ifftn(.real) loop of Split_freq (:2082-2090, via the symmetrised half-spectrum mask).
+#include <stdlib.h>
 #include "common.h"
 
 namespace fcvsr {
@@ -183,8 +184,8 @@ __global__ __launch_bounds__(512) void rfft_rows_kernel(View src, int n, int H, 
                                                         long long ps, int im_off, int re_off, FftPlan plan) {
   extern __shared__ __align__(16) float lds[];
   const int NL = W * L;
-  const int b = blockIdx.x / H, y = blockIdx.x % H;
-  const int c0 = blockIdx.y * 2 * L;
+  const int b = blockIdx.y / H, y = blockIdx.y % H;
+  const int c0 = blockIdx.x * 2 * L;   // channel chunks of one row are dispatched together (they share 128-byte lines)
   const int Wf = W / 2 + 1;
   make_twiddles(lds + 4 * NL, W, false);
   const float* sp = src.p + (long long)b * src.sb + (long long)y * src.sy;
@@ -218,8 +219,8 @@ __global__ __launch_bounds__(512) void fft_cols_kernel(const float* in, float* o
                                                        FftPlan plan) {
   extern __shared__ __align__(16) float lds[];
   const int NL = H * L;
-  const int b = blockIdx.x / Wf, kx = blockIdx.x % Wf;
-  const int c0 = blockIdx.y * L;
+  const int b = blockIdx.y / Wf, kx = blockIdx.y % Wf;
+  const int c0 = blockIdx.x * L;
   make_twiddles(lds + 4 * NL, H, inverse != 0);
   for (int t = threadIdx.x; t < NL; t += blockDim.x) {
     const int l = t & (L - 1), y = t >> (31 - __clz(L));
@@ -249,8 +250,8 @@ __global__ __launch_bounds__(512) void irfft_rows_kernel(const float* spec, long
                                                          int H, int W, int L, View dst, float scale, FftPlan plan) {
   extern __shared__ __align__(16) float lds[];
   const int NL = W * L;
-  const int b = blockIdx.x / H, y = blockIdx.x % H;
-  const int c0 = blockIdx.y * 2 * L;
+  const int b = blockIdx.y / H, y = blockIdx.y % H;
+  const int c0 = blockIdx.x * 2 * L;   // channel chunks of one row are dispatched together (they share 128-byte lines)
   const int Wf = W / 2 + 1;
   make_twiddles(lds + 4 * NL, W, true);
   const float* ip = spec + ((long long)(b * H + y) * Wf) * ps;
@@ -283,10 +284,19 @@ __global__ __launch_bounds__(512) void irfft_rows_kernel(const float* spec, long
   }
 }
 
+static long long lds_budget() {
+  static long long b = -1;
+  if (b < 0) {
+    const char* e = getenv("FCVSR_FFT_LDS_KB");
+    b = (e ? atoll(e) : 64) * 1024;   // measured: 48-64 KiB (2-3 workgroups per CU) is 1.5x faster than 1 fat workgroup
+  }
+  return b;
+}
+
 static int pick_lanes(int N, int n_lanes_needed) {
-  // LDS bytes = 16*N*L + 8*N, budget 128 KiB; L power of two in [1,32]
+  // LDS bytes = 16*N*L + 8*N within the budget; L power of two in [1,32]
   int L = 32;
-  while (L > 1 && (16ll * N * L + 8ll * N) > 128 * 1024) L >>= 1;
+  while (L > 1 && (16ll * N * L + 8ll * N) > lds_budget()) L >>= 1;
   while (L > 1 && L / 2 >= n_lanes_needed) L >>= 1;
   return L;
 }
@@ -314,7 +324,7 @@ extern "C" int fcvsr_rfft2(const fcvsr_view* src, int B, int H, int W, int n, fl
     FCVSR_CHECK_ARG(16ll * W * L + 8ll * W <= 160 * 1024, "row too long for LDS");
     const size_t lds = 16ull * W * L + 8ull * W;
     (void)allow_lds(rfft_rows_kernel, lds);
-    dim3 grid(B * H, cdiv(n, 2 * L));
+    dim3 grid(cdiv(n, 2 * L), B * H);
     hipLaunchKernelGGL(rfft_rows_kernel, grid, dim3(512), lds, st, to_view(*src), n, H, W, L, spec,
                        (long long)pix_stride, im_off, re_off, pw);
     FCVSR_LAUNCH_CHECK();
@@ -324,7 +334,7 @@ extern "C" int fcvsr_rfft2(const fcvsr_view* src, int B, int H, int W, int n, fl
     FCVSR_CHECK_ARG(16ll * H * L + 8ll * H <= 160 * 1024, "column too long for LDS");
     const size_t lds = 16ull * H * L + 8ull * H;
     (void)allow_lds(fft_cols_kernel, lds);
-    dim3 grid(B * Wf, cdiv(n, L));
+    dim3 grid(cdiv(n, L), B * Wf);
     hipLaunchKernelGGL(fft_cols_kernel, grid, dim3(512), lds, st, (const float*)spec, spec, (long long)pix_stride, im_off,
                        re_off, n, H, Wf, L, 0, (const float*)nullptr, ph);
     FCVSR_LAUNCH_CHECK();
@@ -347,7 +357,7 @@ extern "C" int fcvsr_irfft2(const float* spec, int64_t pix_stride, int im_off, i
     FCVSR_CHECK_ARG(16ll * H * L + 8ll * H <= 160 * 1024, "column too long for LDS");
     const size_t lds = 16ull * H * L + 8ull * H;
     (void)allow_lds(fft_cols_kernel, lds);
-    dim3 grid(B * Wf, cdiv(n, L));
+    dim3 grid(cdiv(n, L), B * Wf);
     hipLaunchKernelGGL(fft_cols_kernel, grid, dim3(512), lds, st, spec, mid, (long long)pix_stride, im_off, re_off, n, H,
                        Wf, L, 1, mask, ph);
     FCVSR_LAUNCH_CHECK();
@@ -357,7 +367,7 @@ extern "C" int fcvsr_irfft2(const float* spec, int64_t pix_stride, int im_off, i
     FCVSR_CHECK_ARG(16ll * W * L + 8ll * W <= 160 * 1024, "row too long for LDS");
     const size_t lds = 16ull * W * L + 8ull * W;
     (void)allow_lds(irfft_rows_kernel, lds);
-    dim3 grid(B * H, cdiv(n, 2 * L));
+    dim3 grid(cdiv(n, 2 * L), B * H);
     hipLaunchKernelGGL(irfft_rows_kernel, grid, dim3(512), lds, st, (const float*)mid, (long long)pix_stride, im_off,
                        re_off, n, H, W, L, to_view(*dst), 1.0f / ((float)H * (float)W), pw);
     FCVSR_LAUNCH_CHECK();

@@ -85,8 +85,7 @@ extern "C" int fcvsr_divenh(int mode, int first, const float* f, float* s_f, flo
     FCVSR_CHECK_ARG(scratch_elems >= 2ll * B * nblk * C, "scratch too small");
     hipLaunchKernelGGL((reduce_stage1<2, DivEnhExprF>), dim3(nblk, B), dim3(kRedThreads), 0, st, ex, B, ex.HW, C, scratch);
     FCVSR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_stage2, dim3(cdiv(2ll * B * C, 256)), dim3(256), 0, st, (const float*)scratch, 2 * B, nblk, C,
-                       sums);
+    hipLaunchKernelGGL(reduce_stage2, dim3(2 * B), dim3(kRedThreads), 0, st, (const float*)scratch, 2 * B, nblk, C, sums);
     FCVSR_LAUNCH_CHECK();
   } else {
     FCVSR_CHECK_ARG(g1 && (first || g2), "apply mode needs gates");

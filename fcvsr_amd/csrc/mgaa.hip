@@ -194,8 +194,7 @@ extern "C" int fcvsr_channel_sum(const fcvsr_view* src, int B, int H, int W, flo
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL((reduce_stage1<1, ViewSumF>), dim3(nblk, B), dim3(kRedThreads), 0, st, f, B, npix, src->c, scratch);
   FCVSR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_stage2, dim3(cdiv((long long)B * src->c, 256)), dim3(256), 0, st, (const float*)scratch, B,
-                     nblk, src->c, out);
+  hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(kRedThreads), 0, st, (const float*)scratch, B, nblk, src->c, out);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

@@ -5,7 +5,7 @@
 namespace fcvsr {
 
 constexpr int kRedThreads = 256;
-constexpr int kRedPix = 1024;  // pixels per stage-1 block
+constexpr int kRedPix = 256;   // pixels per stage-1 block (enough blocks to fill 256 CUs at 180x320)
 
 inline int red_blocks(long long npix) { return cdiv(npix, kRedPix); }
 
@@ -43,14 +43,23 @@ __global__ __launch_bounds__(kRedThreads) void reduce_stage1(F f, int B, long lo
   }
 }
 
-// Stage 2: out[kb][c] = sum_blk partial[kb][blk][c]   (kb in [0, K*B))
-static __global__ void reduce_stage2(const float* partial, int KB, int nblk, int C, float* out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= KB * C) return;
-  const int kb = i / C, c = i % C;
+// Stage 2: out[kb][c] = sum_blk partial[kb][blk][c]   (kb in [0, K*B)); one 256-thread block per kb, fixed order
+static __global__ __launch_bounds__(kRedThreads) void reduce_stage2(const float* partial, int KB, int nblk, int C,
+                                                                    float* out) {
+  __shared__ float sm[kRedThreads];
+  const int kb = blockIdx.x;
+  const int R = kRedThreads / C;
+  const int sub = threadIdx.x / C, c = threadIdx.x % C;
   float s = 0.f;
-  for (int blk = 0; blk < nblk; ++blk) s += partial[((long long)kb * nblk + blk) * C + c];
-  out[i] = s;
+  if (sub < R)
+    for (int blk = sub; blk < nblk; blk += R) s += partial[((long long)kb * nblk + blk) * C + c];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float t = 0.f;
+    for (int q = 0; q < R; ++q) t += sm[q * C + threadIdx.x];
+    out[(long long)kb * C + threadIdx.x] = t;
+  }
 }
 
 }  // namespace fcvsr

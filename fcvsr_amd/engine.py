@@ -168,7 +168,7 @@ class Engine:
 
     def _channel_sum(self, t):
         B, H, W, Cc = t.shape
-        nblk = (H * W + 1023) // 1024
+        nblk = (H * W + 255) // 256
         out = self._new(t.device, B, Cc)
         scratch = self._new(t.device, B * nblk * Cc)
         v = view(t)
@@ -318,7 +318,7 @@ class Engine:
         freq = [bands[Q - 1 - i] for i in range(Q)]               # 'l2h' => reversed band list (:2204-2205)
         s_f = self._new(dev, B, H, W, n)
         s_o = self._new(dev, B, H, W, n)
-        nblk = (H * W + 1023) // 1024
+        nblk = (H * W + 255) // 256
         scratch = self._new(dev, 2 * B * nblk * n)
         sums = self._new(dev, 2, B, n)
         inv_hw = 1.0 / (H * W)

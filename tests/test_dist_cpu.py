@@ -1,0 +1,56 @@
+"""CPU, world_size 2, gloo: the clip sharding + max-over-ranks timing logic of the multi-GPU path."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fcvsr_amd.harness.sharding import shard, shard_sequences
+    from fcvsr_amd.harness.windows import window_indices
+    seqs = [100, 100, 41, 34]                     # REDS4-like and Vid4-like lengths
+    mine = shard_sequences(seqs, rank, world)
+    # every rank processes its frames (here: records which LR frames each window needs) with no communication
+    frames = [(s, i, tuple(window_indices(i, 7, seqs[s], "replicate"))) for s, a, b in mine for i in range(a, b)]
+    n = torch.tensor([len(frames)], dtype=torch.int64)
+    t = torch.tensor([0.5 + 0.25 * rank], dtype=torch.float64)      # pretend timings
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                        # bench.py: max over ranks
+    dist.barrier()
+    q.put((rank, frames, [int(c) for c in counts], float(t)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_covers_every_frame_once():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seen = sorted((s, i) for _, frames, _, _ in res for s, i, _ in frames)
+    assert seen == [(s, i) for s, n in enumerate([100, 100, 41, 34]) for i in range(n)]
+    for _, _, counts, tmax in res:
+        assert sum(counts) == 275 and abs(counts[0] - counts[1]) <= 1
+        assert tmax == 0.75
+    from fcvsr_amd.harness.sharding import shard, throughput
+    assert [shard(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert throughput([138, 137], [0.5, 0.75]) == 275 / 0.75

@@ -189,6 +189,10 @@ class _GShiftBase(nn.Module):
         # arithmetic of the conv layers: "f32" = exact f32 (parity mode, default); "bf16" / "f16" = matrix cores with
         # 16-bit operands and f32 accumulation (activations stay f32 in HBM).  Not part of state_dict.
         self.precision = os.environ.get("FCVSR_PRECISION", "f32")
+        # number of HIP streams a batch is split over (independent clips; overlaps memory- and MFMA-bound phases)
+        self.streams = int(os.environ.get("FCVSR_STREAMS", "1"))
+        # capture the launch sequence of a forward in a hipGraph (per input shape) and replay it
+        self.use_graph = os.environ.get("FCVSR_GRAPH", "0") == "1"
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: float (B, 7, C, H, W) in [0,1] on a HIP device -> (B, C, 4H, 4W)."""

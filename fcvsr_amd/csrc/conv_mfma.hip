@@ -35,6 +35,7 @@ struct MGroup {
   View src[3];
   View res[2];
   View dst;
+  float* gc_partial;   // [B][tiles_per_image*4][cout+2] (nullptr = off)
   int B, H, W;         // spatial size (stride-1 "same" conv: output size == input size)
   int tiles_x, tiles_y;
   int tile_begin;      // first flattened tile id of this group
@@ -55,9 +56,10 @@ struct MfmaArgs {
   int ps;
   int flat;            // 1x1: treat pixels as a flat list of B*H*W
   int src16, dst16;    // sources / destination stored in the MFMA dtype (16-bit) instead of f32
+  const float* gc_wmask;   // ContextBlock fusion: per-wave online-softmax partials of the output (cout <= 64, 3x3)
   int planar;          // single f32 source with arbitrary channel stride (the NCHW frames of feat_extract), cin <= 64
   int sub2;            // stride-2 convolution: evaluate at full resolution, keep the even output pixels only
-  int dbg;             // ablation switches for profiling builds (FCVSR_MFMA_DBG): 1 skip staging, 2 skip MFMA, 4 skip stores
+  int dbg;             // ablation switches for profiling builds (FCVSR_MFMA_DBG): 1 skip staging, 2 skip MFMA, 4 skip stores, 8 skip weight loads
 };
 
 template <bool BF16>
@@ -89,15 +91,15 @@ struct EpiCtx {
 // Epilogue for one pixel x 4 consecutive output channels (n..n+3) held as a float4 (after the LDS transpose).
 // Element offsets are 32-bit (host checks every tensor spans < 2^31 elements).
 template <bool BF16>
-__device__ __forceinline__ void epilogue_quad(const EpiCtx& e, float4 v, const float* bias, int cout, int n, int py, int px,
-                                              long long pflat) {
+__device__ __forceinline__ bool epilogue_quad(const EpiCtx& e, float4 v, const float* bias, int cout, int n, int py, int px,
+                                              long long pflat, float4* xo) {
   bool pok = e.flat ? (pflat < e.npix) : ((py < e.H) && (px < e.W));
   if (e.sub2) {                      // stride 2: only even positions exist in the output; res/dst are at half resolution
     pok = pok && !((py | px) & 1);
     py >>= 1;
     px >>= 1;
   }
-  if (!pok || n >= cout) return;
+  if (!pok || n >= cout) return false;
   const bool full = (n + 3 < cout);
   float x[4] = {v.x, v.y, v.z, v.w};
   if (bias) {
@@ -170,6 +172,8 @@ __device__ __forceinline__ void epilogue_quad(const EpiCtx& e, float4 v, const f
 #pragma unroll
     for (int q = 0; q < 4; ++q) if (n + q < cout) d.p[o + (nn + q) * (int)d.sc] = x[q];
   }
+  *xo = make_float4(x[0], n + 1 < cout ? x[1] : 0.f, n + 2 < cout ? x[2] : 0.f, n + 3 < cout ? x[3] : 0.f);
+  return true;
 }
 
 template <bool BF16, int NT, int KS, int MW>
@@ -329,6 +333,7 @@ __global__ __launch_bounds__(256, MW == 1 ? (NT == 128 ? 3 : 4) : 2) void conv_m
 #define FCVSR_FETCH_W(TAP)                                                                             \
   do {                                                                                                 \
     const uint16_t* wp_ = wbase + (TAP) * wtap;                                                        \
+    if (a.dbg & 8) break;                                                                              \
     w0 = *reinterpret_cast<const uint4*>(wp_);                                                         \
     if (WLOADS > 1) w1 = *reinterpret_cast<const uint4*>(wp_ + wrow32);                                \
     if (WLOADS > 2) w2 = *reinterpret_cast<const uint4*>(wp_ + 2 * wrow32);                            \
@@ -394,16 +399,88 @@ __global__ __launch_bounds__(256, MW == 1 ? (NT == 128 ? 3 : 4) : 2) void conv_m
           E_s[((i & 3) + 8 * (i >> 2) + 4 * h) * EROW + nf2 * 32 + r] = acc[m][nh * (EW / 32) + nf2][i];
       }
       __builtin_amdgcn_wave_barrier();
+      float gm = -INFINITY, gs = 0.f;                     // ContextBlock partials of this lane group (online softmax)
+      float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int j = 0; j < 32 * QPR / 64; ++j) {
         const int idx = j * 64 + lane;
         const int cq = idx % QPR, p = idx / QPR;
         const float4 v = *reinterpret_cast<const float4*>(E_s + p * EROW + cq * 4);
+        const int n = n0 + nh * EW + cq * 4;
+        float4 xo = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool valid = false;
         if (!(a.dbg & 4) || v.x == 12345.678f)
-          epilogue_quad<BF16>(e, v, a.bias, a.cout, n0 + nh * EW + cq * 4, ty0 + yo, tx0 + p, flat0 + yo * kTW + p);
+          valid = epilogue_quad<BF16>(e, v, a.bias, a.cout, n, ty0 + yo, tx0 + p, flat0 + yo * kTW + p, &xo);
+        if (a.gc_wmask) {
+          // logit of pixel p = <r_p, wmask> summed over the QPR lanes that hold the pixel (ContextBlock.conv_mask, :676)
+          float part = 0.f;
+          if (valid) {
+            const float4 wm = *reinterpret_cast<const float4*>(a.gc_wmask + n);
+            part = xo.x * wm.x + (n + 1 < a.cout ? xo.y * wm.y : 0.f) + (n + 2 < a.cout ? xo.z * wm.z : 0.f) +
+                   (n + 3 < a.cout ? xo.w * wm.w : 0.f);
+          }
+#pragma unroll
+          for (int o = QPR / 2; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+          const bool pval = (ty0 + yo < G.H) && (tx0 + p < G.W);
+          if (pval) {
+            const float mn = fmaxf(gm, part);
+            const float sc = expf(gm - mn);                 // gm = -inf on the first valid pixel -> 0
+            const float ee = expf(part - mn);
+            gs = gs * sc + ee;
+            ga.x = ga.x * sc + ee * xo.x; ga.y = ga.y * sc + ee * xo.y; ga.z = ga.z * sc + ee * xo.z; ga.w = ga.w * sc + ee * xo.w;
+            gm = mn;
+          }
+        }
         asm volatile("" ::: "memory");
       }
+      if (a.gc_wmask && G.gc_partial) {
+        // combine the 64/QPR lane groups of the wave, then lanes 0..QPR-1 write the wave's partial
+#pragma unroll
+        for (int o = QPR; o < 64; o <<= 1) {
+          const float om = __shfl_xor(gm, o), os = __shfl_xor(gs, o);
+          const float ox = __shfl_xor(ga.x, o), oy = __shfl_xor(ga.y, o), oz = __shfl_xor(ga.z, o), ow = __shfl_xor(ga.w, o);
+          const float mn = fmaxf(gm, om);
+          const float s1 = (gm == -INFINITY) ? 0.f : expf(gm - mn), s2 = (om == -INFINITY) ? 0.f : expf(om - mn);
+          gs = gs * s1 + os * s2;
+          ga.x = ga.x * s1 + ox * s2; ga.y = ga.y * s1 + oy * s2; ga.z = ga.z * s1 + oz * s2; ga.w = ga.w * s1 + ow * s2;
+          gm = mn;
+        }
+        // per-wave partial -> LDS (behind the 4 transpose areas); combined across the 4 waves below
+        float* gw = reinterpret_cast<float*>(lds) + 4 * 32 * EROW + wave * (EW + 4);
+        if (lane < QPR) {
+          *reinterpret_cast<float4*>(gw + lane * 4) = ga;
+          if (lane == 0) { gw[EW] = gm; gw[EW + 1] = gs; }
+        }
+      }
       __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (a.gc_wmask && G.gc_partial && NT <= 64 && MW == 1) {
+    // one partial per workgroup: waves combined in fixed order (deterministic), written by wave 0
+    __syncthreads();
+    if (wave == 0 && lane < QPR) {
+      const float* g0 = reinterpret_cast<const float*>(lds) + 4 * 32 * EROW;
+      float m = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) m = fmaxf(m, g0[w * (EW + 4) + EW]);
+      float sum = 0.f;
+      float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float mw = g0[w * (EW + 4) + EW];
+        const float sc = (mw == -INFINITY) ? 0.f : expf(mw - m);
+        sum = fmaf(g0[w * (EW + 4) + EW + 1], sc, sum);
+        const float4 v = *reinterpret_cast<const float4*>(g0 + w * (EW + 4) + lane * 4);
+        acc4.x = fmaf(v.x, sc, acc4.x); acc4.y = fmaf(v.y, sc, acc4.y); acc4.z = fmaf(v.z, sc, acc4.z); acc4.w = fmaf(v.w, sc, acc4.w);
+      }
+      const int per_img = G.tiles_x * G.tiles_y;
+      float* pp = G.gc_partial + ((long long)b * per_img + (tl % per_img)) * (a.cout + 2);
+      const int n = lane * 4;
+      if (n < a.cout) pp[n] = acc4.x;
+      if (n + 1 < a.cout) pp[n + 1] = acc4.y;
+      if (n + 2 < a.cout) pp[n + 2] = acc4.z;
+      if (n + 3 < a.cout) pp[n + 3] = acc4.w;
+      if (lane == 0) { pp[a.cout] = m; pp[a.cout + 1] = sum; }
     }
   }
 }
@@ -413,7 +490,7 @@ static hipError_t launch_mfma(const MfmaArgs& a, int total_tiles, hipStream_t st
   constexpr int PAD = KS / 2;
   constexpr int kTH = 4 * MW;
   size_t lds = ((size_t)(kTH + 2 * PAD) * (kTW + 2 * PAD) * kLD + (size_t)NT * kLD) * sizeof(uint16_t);
-  const size_t epi = 4ull * 32 * ((NT >= 64 ? 64 : 32) + 4) * sizeof(float);     // epilogue transpose area
+  const size_t epi = (4ull * 32 + 4) * ((NT >= 64 ? 64 : 32) + 4) * sizeof(float);   // epilogue transpose + GC partial areas
   if (lds < epi) lds = epi;
   static bool attr_done = false;
   if (!attr_done) {
@@ -503,6 +580,10 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   a.rs[1] = d0.res_scale[1];
   a.ps = d0.pixel_shuffle;
   a.flat = d0.kh == 1 ? 1 : 0;
+  a.gc_wmask = d0.gc_wmask;
+  FCVSR_CHECK_ARG(d0.gc_wmask == nullptr || (d0.kh == 3 && d0.stride == 1 && d0.cout <= 64 && !d0.pixel_shuffle &&
+                                             ((uintptr_t)d0.gc_wmask % 16) == 0),
+                  "ContextBlock fusion: 3x3 stride-1 layer with cout <= 64");
   {
     const char* dbg = getenv("FCVSR_MFMA_DBG");
     a.dbg = dbg ? atoi(dbg) : 0;
@@ -544,6 +625,8 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
     G.dst = to_view(d.dst);
     if (a.flat && !d.pixel_shuffle)
       FCVSR_CHECK_ARG(d.dst.sy == d.dst.sx * d.W && d.dst.sb == d.dst.sy * d.H, "1x1 needs uniformly strided dst");
+    G.gc_partial = d.gc_partial;
+    FCVSR_CHECK_ARG((d.gc_wmask == nullptr) == (d.gc_partial == nullptr) && d.gc_wmask == d0.gc_wmask, "gc fields: all groups alike");
     G.B = d.B; G.H = d.H; G.W = d.W;
     G.tile_begin = tiles;
     if (a.flat) {

@@ -215,6 +215,17 @@ extern "C" int fcvsr_gc_context(const float* r, const float* wmask, const float*
   return 0;
 }
 
+extern "C" int fcvsr_gc_finish(const float* partial, int nparts, const float* w1, const float* w2, int B, int C, float* add,
+                               void* stream) {
+  FCVSR_CHECK_ARG(partial && w1 && w2 && add, "null pointer");
+  FCVSR_CHECK_ARG(B > 0 && nparts > 0 && C >= 4 && C <= 256, "bad sizes");
+  FCVSR_CHECK_ARG((2ll * C + nparts) * 4 <= 60 * 1024, "too many partials for stage-2 LDS");
+  hipLaunchKernelGGL(gc_stage2_kernel, dim3(B), dim3(256), (2 * C + nparts) * sizeof(float), (hipStream_t)stream, partial,
+                     nparts, C, w1, w2, add);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int fcvsr_gc_apply(const float* r, const float* add, const float* z, float* out, float slope, int B, int H,
                               int W, int C, void* stream) {
   FCVSR_CHECK_ARG(r && add && z && out, "null pointer");

@@ -61,6 +61,9 @@ class Engine:
         self._versions: Optional[Tuple] = None
         self._dev_masks: Dict[Tuple, torch.Tensor] = {}
         self._par: Dict[str, torch.Tensor] = {}
+        self._streams: List[torch.cuda.Stream] = []
+        self._graphs: Dict[Tuple, Tuple] = {}
+        self._pack_epoch = 0
         self._warned = False
         self.taps: Optional[dict] = None       # set to a dict to record NCHW copies of intermediate results (tests)
 
@@ -82,6 +85,7 @@ class Engine:
             if v.device != dev:
                 raise RuntimeError(f"parameter {k} is on {v.device}, input on {dev}: call model.to(device) first")
         self._packed = {}
+        self._pack_epoch += 1
         self._par = sd
         self._versions = ver
 
@@ -136,7 +140,7 @@ class Engine:
         return dst
 
     def _convg(self, name, groups, *, stride=1, act=ACT_NONE, slope=0.0, slope_t=None, res_scale=(), ps=False,
-               freq=False, direct=False, force_f16=False):
+               freq=False, direct=False, force_f16=False, gc_wmask=None):
         """One conv layer applied to 1..3 tensors that share its weights (pyramid levels): a single grouped MFMA launch in
         the 16-bit modes, per-tensor exact-f32 direct launches otherwise."""
         ksz = self._par[name + ".weight"].shape[-1]
@@ -151,12 +155,14 @@ class Engine:
                 dt = torch.float16
             w, b, cout, _ = self._weights(name, dt, ps)
             hip.conv2d_mfma(groups, w, ksz, cout, hip.BF16 if dt == torch.bfloat16 else hip.F16, stride=stride, bias=b, act=act,
-                            slope=slope, slope_t=slope_t, res_scale=res_scale, pixel_shuffle=ps, name=name)
-            return
+                            slope=slope, slope_t=slope_t, res_scale=res_scale, pixel_shuffle=ps, gc_wmask=gc_wmask,
+                            name=name)
+            return True
         w, b, cout, _ = self._weights(name, "direct")
         for g in groups:
             hip.conv2d(g["srcs"], w, ksz, cout, g["dst"], bias=b, stride=stride, act=act, slope=slope, slope_t=slope_t,
                        res=g.get("res", ()), res_scale=res_scale, pixel_shuffle=ps, name=name)
+        return False
 
     def _tap(self, name, t_nhwc):
         if self.taps is not None:
@@ -363,19 +369,27 @@ class Engine:
         self._convg(pre + ".body.0", [dict(srcs=[x], dst=t) for x, t in zip(xs, t1)], act=ACT_LEAKY, slope=0.1)
         self._convg(pre + ".body.2", [dict(srcs=[a], dst=t) for a, t in zip(t1, t2)])
         self._convg(pre + ".RCB.body.0", [dict(srcs=[a], dst=t) for a, t in zip(t2, r1)], act=ACT_LEAKY, slope=0.2)
-        self._convg(pre + ".RCB.body.2", [dict(srcs=[a], dst=t) for a, t in zip(r1, rr)])
+        # ContextBlock: in the MFMA modes the softmax-pooling partials come out of the conv epilogue (no extra pass over r)
+        wmask = par[pre + ".RCB.gcnet.conv_mask.weight"]
+        w1g, w2g = par[pre + ".RCB.gcnet.channel_add_conv.0.weight"], par[pre + ".RCB.gcnet.channel_add_conv.2.weight"]
+        nparts = [((x.shape[1] + 3) // 4) * ((x.shape[2] + 31) // 32) for x in xs]
+        parts = [self._new(x.device, x.shape[0], npt, n + 2) for x, npt in zip(xs, nparts)]
+        fused_gc = self._convg(pre + ".RCB.body.2", [dict(srcs=[a], dst=t, gc_partial=pt) for a, t, pt in zip(r1, rr, parts)],
+                               gc_wmask=wmask if self.precision != "f32" else None)
         R = []
         for l, x in enumerate(xs):
             dev = x.device
             B, H, W, _ = x.shape
             r = rr[l]
             add = self._new(dev, B, n)
-            nblk = (H * W + 255) // 256
-            scratch = self._new(dev, B * nblk * (n + 2))
-            check(L.fcvsr_gc_context(r.data_ptr(), par[pre + ".RCB.gcnet.conv_mask.weight"].data_ptr(),
-                                     par[pre + ".RCB.gcnet.channel_add_conv.0.weight"].data_ptr(),
-                                     par[pre + ".RCB.gcnet.channel_add_conv.2.weight"].data_ptr(), B, H, W, n,
-                                     add.data_ptr(), scratch.data_ptr(), scratch.numel(), st), "fcvsr_gc_context")
+            if fused_gc:
+                check(L.fcvsr_gc_finish(parts[l].data_ptr(), nparts[l], w1g.data_ptr(), w2g.data_ptr(), B, n,
+                                        add.data_ptr(), st), "fcvsr_gc_finish")
+            else:
+                nblk = (H * W + 255) // 256
+                scratch = self._new(dev, B * nblk * (n + 2))
+                check(L.fcvsr_gc_context(r.data_ptr(), wmask.data_ptr(), w1g.data_ptr(), w2g.data_ptr(), B, H, W, n,
+                                         add.data_ptr(), scratch.data_ptr(), scratch.numel(), st), "fcvsr_gc_context")
             Rl = self._new(dev, B, H, W, n)
             check(L.fcvsr_gc_apply(r.data_ptr(), add.data_ptr(), t2[l].data_ptr(), Rl.data_ptr(), 0.2, B, H, W, n, st),
                   "fcvsr_gc_apply")
@@ -435,10 +449,53 @@ class Engine:
             raise ValueError("H and W must be multiples of 4 (3-level pyramid, reference BlockRCB :766-777)")
         dev = x.device
         with torch.cuda.device(dev):
-            return self._forward(x.contiguous().float(), m, B, T, Cimg, H, W, dev)
+            x = x.contiguous().float()
+            self._refresh(dev)
+            ns = max(1, min(int(getattr(m, "streams", 1)), B))
+            if not getattr(m, "use_graph", False) or self.taps is not None or hip.PROFILE is not None:
+                return self._run(x, m, ns, dev)
+            # hipGraph mode: the ~650 launches of one forward are captured once per (shape, precision, streams, weights
+            # version) and replayed, which removes the host launch cost (~9 us per ctypes launch) from the critical path.
+            key = (tuple(x.shape), self.precision, ns, str(dev), self._pack_epoch)
+            ent = self._graphs.get(key)
+            if ent is None:
+                sx = x.clone()
+                for _ in range(2):                       # eager warm-up: weight packing, masks, function attributes
+                    self._run(sx, m, ns, dev)
+                torch.cuda.synchronize(dev)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    so = self._run(sx, m, ns, dev)
+                self._graphs = {k: v for k, v in self._graphs.items() if k[4] == self._pack_epoch}
+                ent = self._graphs[key] = (graph, sx, so)
+            graph, sx, so = ent
+            sx.copy_(x)
+            graph.replay()
+            return so.clone()
 
-    def _forward(self, x, m, B, T, Cimg, H, W, dev):
-        self._refresh(dev)
+    def _run(self, x, m, ns, dev):
+        B, T, Cimg, H, W = x.shape
+        if ns == 1:
+            return self._forward(x, m, B, T, Cimg, H, W, dev)
+        # Clips are independent: run sub-batches on separate HIP streams.  Every kernel of the path has serial phases
+        # (stage -> MFMA -> store); with several forwards in flight the hardware interleaves workgroups of different
+        # kernels, so HBM-bound and MFMA-bound phases of different sub-batches overlap and launch tails are filled.
+        out = self._new(dev, B, Cimg, 4 * H, 4 * W)
+        cur = torch.cuda.current_stream(dev)
+        while len(self._streams) < ns:
+            self._streams.append(torch.cuda.Stream(device=dev))
+        bounds = [round(i * B / ns) for i in range(ns + 1)]
+        for i in range(ns):
+            st = self._streams[i]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                xs = x[bounds[i]:bounds[i + 1]]
+                self._forward(xs, m, xs.shape[0], T, Cimg, H, W, dev, out=out[bounds[i]:bounds[i + 1]])
+        for i in range(ns):
+            cur.wait_stream(self._streams[i])
+        return out
+
+    def _forward(self, x, m, B, T, Cimg, H, W, dev, out=None):
         n = m.n_feats
         L = lib()
         st = stream_ptr()
@@ -480,7 +537,8 @@ class Engine:
         self._conv("upconv1", [fz], u1, act=ACT_PRELU, slope_t=a_t, ps=True)
         u2 = self._new(dev, B, 4 * H, 4 * W, n, dtype=self._adt())
         self._conv("upconv2", [u1], u2, act=ACT_PRELU, slope_t=a_t, ps=True)
-        out = self._new(dev, B, Cimg, 4 * H, 4 * W)               # NCHW boundary tensor
+        if out is None:
+            out = self._new(dev, B, Cimg, 4 * H, 4 * W)           # NCHW boundary tensor
         out_v = out.permute(0, 2, 3, 1)
         centre = x[:, T // 2].permute(0, 2, 3, 1)                 # (B,H,W,Cimg) view of the centre LR frame
         cv, ov = view(centre), view(out_v)

@@ -30,7 +30,8 @@ class ConvDesc(C.Structure):
                 ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("cout", C.c_int32), ("weight", C.c_void_p), ("cout_pad", C.c_int32), ("bias", C.c_void_p),
                 ("act", C.c_int32), ("slope", C.c_float), ("slope_ptr", C.c_void_p), ("n_res", C.c_int32),
-                ("res", View * 2), ("res_scale", C.c_float * 2), ("dst", View), ("pixel_shuffle", C.c_int32)]
+                ("res", View * 2), ("res_scale", C.c_float * 2), ("dst", View), ("pixel_shuffle", C.c_int32),
+                ("gc_wmask", C.c_void_p), ("gc_partial", C.c_void_p)]
 
 
 # bench.py instrumentation: when PROFILE is a list, every conv launch is bracketed by HIP events on the launch stream and
@@ -68,6 +69,7 @@ SIGNATURES = {
     "fcvsr_divenh": [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _F, _VP, _VP, _VP, _VP, _I64, _I, _I, _I, _I, _VP],
     "fcvsr_scale_add": [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP],
     "fcvsr_gc_context": [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _I64, _VP],
+    "fcvsr_gc_finish": [_VP, _I, _VP, _VP, _I, _I, _VP, _VP],
     "fcvsr_gc_apply": [_VP, _VP, _VP, _VP, _F, _I, _I, _I, _I, _VP],
     "fcvsr_xscale": [_VP, _VP, _F, _VP, _VP, _VP, _I, _I, _I, _I, _VP],
     "fcvsr_pixel_shuffle": [_VP, _VP, _I, _I, _I, _I, _VP],
@@ -191,7 +193,7 @@ def mfma_eligible(ksize: int, stride: int, groups) -> bool:
 def conv2d_mfma(groups, wpacked: torch.Tensor, ksize: int, cout: int, mma_dtype: int, *, stride: int = 1,
                 bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, slope: float = 0.0,
                 slope_t: Optional[torch.Tensor] = None, res_scale: Sequence[float] = (), pixel_shuffle: bool = False,
-                name: str = ""):
+                gc_wmask: Optional[torch.Tensor] = None, name: str = ""):
     """groups: 1..3 dicts {srcs: [..], dst: t, res: [..]} sharing weights / epilogue (one launch)."""
     n = len(groups)
     descs = (ConvDesc * n)()
@@ -200,6 +202,9 @@ def conv2d_mfma(groups, wpacked: torch.Tensor, ksize: int, cout: int, mma_dtype:
         cin = _fill_desc(descs[i], g["srcs"], wpacked, ksize, cout, wpacked.shape[1], g["dst"], bias, stride, act, slope,
                          slope_t, g.get("res", ()), res_scale, pixel_shuffle)
         assert wpacked.shape[0] == ksize * ksize and wpacked.shape[2] >= cin, (wpacked.shape, ksize, cin)
+        if gc_wmask is not None:
+            descs[i].gc_wmask = gc_wmask.data_ptr()
+            descs[i].gc_partial = g["gc_partial"].data_ptr()
         flops += 2.0 * descs[i].B * descs[i].H * descs[i].W * cout * cin * ksize * ksize / (stride * stride)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -63,6 +63,11 @@ typedef struct fcvsr_conv_desc {
   float       res_scale[2];
   fcvsr_view  dst;            /* output window; if pixel_shuffle: (2*Ho, 2*Wo) spatial, cout/4 channels */
   int32_t     pixel_shuffle;  /* 0/1: out[c,2h+i,2w+j] = conv[4c+2i+j,h,w] (:2633-2642) */
+  /* fcvsr_conv2d_mfma only: ContextBlock fusion (:657-701).  When both are non-NULL the epilogue also emits, per workgroup,
+   * online-softmax partials of the layer output r: sum_p exp(l_p - m) r_p[c], m = max l_p, sum exp, with l_p = <r_p, gc_wmask>.
+   * gc_partial: [B][ceil(H/4)*ceil(W/32)][cout+2] floats (one per 4x32 tile); combine with fcvsr_gc_finish. */
+  const float* gc_wmask;
+  float*       gc_partial;
 } fcvsr_conv_desc;
 
 const char* fcvsr_last_error(void);
@@ -143,6 +148,9 @@ int fcvsr_scale_add(const float* z, const float* gate, const float* x, float* ou
  *   scratch: B*nblk*(C+2) floats */
 int fcvsr_gc_context(const float* r, const float* wmask, const float* w1, const float* w2, int B, int H, int W, int C,
                      float* add, float* scratch, int64_t scratch_elems, void* stream);
+/* second half of fcvsr_gc_context for partials produced by the fused conv epilogue (or any producer of the same layout) */
+int fcvsr_gc_finish(const float* partial, int nparts, const float* w1, const float* w2, int B, int C, float* add,
+                    void* stream);
 /* RCB tail (:722-725): out = lrelu0.2(r + add[b][c]) + z */
 int fcvsr_gc_apply(const float* r, const float* add, const float* z, float* out, float slope,
                    int B, int H, int W, int C, void* stream);

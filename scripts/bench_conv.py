@@ -32,6 +32,28 @@ def run(name, B, levels, cin, cout, k, iters=30):
 
 
 L3 = [(180, 320), (90, 160), (45, 80)]
+if os.environ.get("ABL2"):
+    def run2(name, B, levels, cin, cout, k, dst16, iters=20):
+        w = torch.randn(cout, cin, k, k, device="cuda") / (cin * k * k) ** 0.5
+        wp = hip.pack_conv_weight_mfma(w, dt)
+        groups = []; flops = 0
+        for (H, W) in levels:
+            x = torch.randn(B, H, W, cin, device="cuda")
+            y = torch.empty(B, H, W, cout, device="cuda", dtype=dt if dst16 else torch.float32)
+            groups.append(dict(srcs=[x], dst=y)); flops += 2.0 * B * H * W * cin * cout * k * k
+        for _ in range(3): hip.conv2d_mfma(groups, wp, k, cout, mdt, act=hip.ACT_LEAKY, slope=0.1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters): hip.conv2d_mfma(groups, wp, k, cout, mdt, act=hip.ACT_LEAKY, slope=0.1)
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        print(f"  {name:30s} {us:8.1f} us {flops/us/1e6:7.1f} TF/s", flush=True)
+    for dbg in (0, 8, 1, 9, 2, 4, 13, 15):
+        os.environ["FCVSR_MFMA_DBG"] = str(dbg)
+        print("dbg", dbg, "(1 staging, 2 MFMA, 4 stores, 8 weights skipped)")
+        run2("64->128 bf16out L0-2 B=4", 4, L3, 64, 128, 3, True)
+        run2("64->64 f32out L0-2 B=4", 4, L3, 64, 64, 3, False)
+    sys.exit(0)
 if os.environ.get("MWTEST"):
     for mw in ("2", "1"):
         os.environ["FCVSR_MFMA_MW"] = mw

@@ -91,6 +91,36 @@ def test_conv_mfma_stride2_and_planar_source():
     assert float((nchw(dst) - ref).abs().max()) < 2e-5 * float(ref.abs().max())
 
 
+def test_conv_mfma_fused_context_block_partials():
+    """ContextBlock pooling (softmax over H*W of <r, wmask>, :657-701) from the conv epilogue's per-wave partials ==
+    the stand-alone two-stage kernel == the torch formula, all evaluated on the conv's own output r."""
+    from fcvsr_amd import hip
+    L = hip.lib()
+    B, Cc, H, W = 2, 64, 22, 70                        # partial tiles: 22 = 5*4+2 rows, 70 = 2*32+6 cols
+    x = nhwc(_rand(B, Cc, H, W))
+    w = _rand(Cc, Cc, 3, 3, seed=1) / 24
+    wm, w1, w2 = _rand(Cc, seed=2).cuda(), (_rand(Cc, Cc, seed=3) / 8).cuda(), (_rand(Cc, Cc, seed=4) / 8).cuda()
+    r = torch.empty(B, H, W, Cc, device="cuda")
+    nparts = ((H + 3) // 4) * ((W + 31) // 32)
+    parts = torch.full((B, nparts, Cc + 2), float("nan"), device="cuda")
+    hip.conv2d_mfma([dict(srcs=[x], dst=r, gc_partial=parts)], hip.pack_conv_weight_mfma(w.cuda(), torch.bfloat16), 3, Cc,
+                    hip.BF16, gc_wmask=wm)
+    add = torch.empty(B, Cc, device="cuda")
+    hip.check(L.fcvsr_gc_finish(parts.data_ptr(), nparts, w1.data_ptr(), w2.data_ptr(), B, Cc, add.data_ptr(),
+                                hip.stream_ptr()), "gc_finish")
+    add2 = torch.empty(B, Cc, device="cuda")
+    nblk = (H * W + 255) // 256
+    scratch = torch.empty(B * nblk * (Cc + 2), device="cuda")
+    hip.check(L.fcvsr_gc_context(r.data_ptr(), wm.data_ptr(), w1.data_ptr(), w2.data_ptr(), B, H, W, Cc, add2.data_ptr(),
+                                 scratch.data_ptr(), scratch.numel(), hip.stream_ptr()), "gc_context")
+    rr = r.cpu().reshape(B, H * W, Cc)
+    m = torch.softmax(rr @ wm.cpu(), dim=1)
+    ctx = (rr * m[..., None]).sum(1)
+    ref = F.leaky_relu(ctx @ w1.cpu().T, 0.2) @ w2.cpu().T
+    assert float((add.cpu() - ref).abs().max()) < 1e-5
+    assert float((add2.cpu() - ref).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 def test_conv_mfma_16bit_storage_is_bit_identical(dt):
     """A 16-bit intermediate between two MFMA convs gives exactly the result of an f32 intermediate (the consumer rounds

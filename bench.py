@@ -51,14 +51,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8, help="7-frame windows per step per GPU (clips are independent)")
+    ap.add_argument("--batch", type=int, default=16, help="7-frame windows per step per GPU (clips are independent)")
     ap.add_argument("--model", choices=["S", "full"], default="S")
     ap.add_argument("--height", type=int, default=180)
     ap.add_argument("--width", type=int, default=320)
     ap.add_argument("--precision", choices=["f32", "bf16", "f16"], default="bf16",
                     help="conv arithmetic: bf16/f16 MFMA operands with f32 accumulate (BASELINE config), or exact f32")
-    ap.add_argument("--streams", type=int, default=1, help="HIP streams the batch is split over")
-    ap.add_argument("--graph", type=int, default=0, help="1: replay the forward from a captured hipGraph")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the batch is split over")
+    ap.add_argument("--graph", type=int, default=1, help="1: replay the forward from a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -126,9 +126,11 @@ def main():
         # Dominant kernel class = the convolution kernel (>= 98 % of FLOPs).  One extra instrumented step: every conv launch
         # is bracketed by HIP events on the launch stream; achieved = sum(algorithmic FLOPs) / sum(durations).
         hip.PROFILE = []
+        model.streams, model.use_graph = 1, False          # one stream, eager launches: isolated per-launch durations
         with torch.no_grad():
             model(x)
         torch.cuda.synchronize()
+        model.streams, model.use_graph = args.streams, bool(args.graph)
         recs = hip.PROFILE
         hip.PROFILE = None
         kind = "direct" if args.precision == "f32" else "mfma"
@@ -170,7 +172,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"FCVSR-{args.model} 4x inference, {B}x7x{H}x{W} -> {4*H}x{4*W} synthetic clips, "
-                                   f"random-init (key-seeded) weights", "batch_per_gpu": B, "parallelism": f"clip-dp{world}"},
+                                   f"random-init (key-seeded) weights", "batch_per_gpu": B, "streams_per_gpu": args.streams, "hipgraph": bool(args.graph),
+                       "parallelism": f"clip-dp{world}"},
             "frames_per_sec_per_gpu": round(fps / world, 3),
             "conv_tflops_end_to_end": round(fps * conv_flops_live(args.model, H, W) / 1e12, 3),
             "roofline": roofline, "cpu_baseline": cpu,

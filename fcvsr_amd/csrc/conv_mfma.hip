@@ -176,6 +176,50 @@ __device__ __forceinline__ bool epilogue_quad(const EpiCtx& e, float4 v, const f
   return true;
 }
 
+// Fast path for 16-bit destinations: one pixel x 8 consecutive output channels per lane = one 16-byte store
+// (no pixel shuffle, channel-contiguous dst, cout % 8 == 0; residuals are f32 views).
+template <bool BF16>
+__device__ __forceinline__ void epilogue_oct(const EpiCtx& e, float4 va, float4 vb, const float* bias, int n, int py, int px,
+                                             long long pflat) {
+  bool pok = e.flat ? (pflat < e.npix) : ((py < e.H) && (px < e.W));
+  if (e.sub2) {
+    pok = pok && !((py | px) & 1);
+    py >>= 1;
+    px >>= 1;
+  }
+  if (!pok) return;
+  float x[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+  if (bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + n), b1 = *reinterpret_cast<const float4*>(bias + n + 4);
+    x[0] += b0.x; x[1] += b0.y; x[2] += b0.z; x[3] += b0.w; x[4] += b1.x; x[5] += b1.y; x[6] += b1.z; x[7] += b1.w;
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    if (e.act == FCVSR_ACT_RELU) x[q] = fmaxf(x[q], 0.f);
+    else if (e.act == FCVSR_ACT_LEAKY || e.act == FCVSR_ACT_PRELU) x[q] = x[q] >= 0.f ? x[q] : x[q] * e.slope;
+  }
+#pragma unroll
+  for (int ri = 0; ri < 2; ++ri) {
+    if (ri < e.n_res) {
+      const View& rv = ri == 0 ? e.res0 : e.res1;
+      const float rs = ri == 0 ? e.rs0 : e.rs1;
+      const int o = (e.flat ? (int)pflat * (int)rv.sx : (e.b * (int)rv.sb + py * (int)rv.sy + px * (int)rv.sx));
+      if (rv.sc == 1) {
+        const float4 r0 = *reinterpret_cast<const float4*>(rv.p + o + n), r1 = *reinterpret_cast<const float4*>(rv.p + o + n + 4);
+        x[0] = fmaf(rs, r0.x, x[0]); x[1] = fmaf(rs, r0.y, x[1]); x[2] = fmaf(rs, r0.z, x[2]); x[3] = fmaf(rs, r0.w, x[3]);
+        x[4] = fmaf(rs, r1.x, x[4]); x[5] = fmaf(rs, r1.y, x[5]); x[6] = fmaf(rs, r1.z, x[6]); x[7] = fmaf(rs, r1.w, x[7]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = fmaf(rs, rv.p[o + (n + q) * (int)rv.sc], x[q]);
+      }
+    }
+  }
+  const View& d = e.dst;
+  const int o = (e.flat ? (int)pflat * (int)d.sx : (e.b * (int)d.sb + py * (int)d.sy + px * (int)d.sx));
+  const uint2 lo = cvt4<BF16>(make_float4(x[0], x[1], x[2], x[3])), hi = cvt4<BF16>(make_float4(x[4], x[5], x[6], x[7]));
+  *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.p) + o + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
 template <bool BF16, int NT, int KS, int MW>
 __global__ __launch_bounds__(256, MW == 1 ? (NT == 128 ? 3 : 4) : 2) void conv_mfma_kernel(MfmaArgs a) {
   constexpr int kTH = 4 * MW;                       // MW tile rows (M-fragments) per wave
@@ -387,6 +431,7 @@ __global__ __launch_bounds__(256, MW == 1 ? (NT == 128 ? 3 : 4) : 2) void conv_m
   constexpr int QPR = EW / 4;                   // float4 per pixel row
   __syncthreads();                              // every wave is done with A_s / B_s
   float* E_s = reinterpret_cast<float*>(lds) + wave * (32 * EROW);
+  const bool oct_path = a.dst16 && !a.ps && !a.gc_wmask && (a.cout % 8 == 0) && G.dst.sc == 1;
 #pragma unroll
   for (int m = 0; m < MW; ++m) {
     const int yo = MW * wave + m;
@@ -401,6 +446,20 @@ __global__ __launch_bounds__(256, MW == 1 ? (NT == 128 ? 3 : 4) : 2) void conv_m
       __builtin_amdgcn_wave_barrier();
       float gm = -INFINITY, gs = 0.f;                     // ContextBlock partials of this lane group (online softmax)
       float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (oct_path) {
+        constexpr int OPR = EW / 8;                       // lanes per pixel at 8 couts per lane
+#pragma unroll
+        for (int j = 0; j < 32 * OPR / 64; ++j) {
+          const int idx = j * 64 + lane;
+          const int co = idx % OPR, p = idx / OPR;
+          const float4 va = *reinterpret_cast<const float4*>(E_s + p * EROW + co * 8);
+          const float4 vb = *reinterpret_cast<const float4*>(E_s + p * EROW + co * 8 + 4);
+          const int n = n0 + nh * EW + co * 8;
+          if (n < a.cout && (!(a.dbg & 4) || va.x == 12345.678f))
+            epilogue_oct<BF16>(e, va, vb, a.bias, n, ty0 + yo, tx0 + p, flat0 + yo * kTW + p);
+          asm volatile("" ::: "memory");
+        }
+      } else
 #pragma unroll
       for (int j = 0; j < 32 * QPR / 64; ++j) {
         const int idx = j * 64 + lane;

@@ -7,7 +7,8 @@ import torch
 
 
 def state_dict_shapes(ctor: str, **kwargs) -> Dict[str, Tuple[int, ...]]:
-    from . import CVSR_freq
+    from . import CVSR_freq, fcvsr_rgb
+    mod = CVSR_freq if hasattr(CVSR_freq, ctor) else fcvsr_rgb
     with torch.device("meta"):
-        m = getattr(CVSR_freq, ctor)(**kwargs)
+        m = getattr(mod, ctor)(**kwargs)
     return {k: tuple(v.shape) for k, v in m.state_dict().items()}

@@ -3,14 +3,14 @@ import os, sys, time
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests")))
 import torch
-from helpers import CASES, load_case, weights_for
+from helpers import CASES, load_case, weights_for, get_ctor
 from fcvsr_amd.arch import CVSR_freq as A
 
 prec = os.environ.get("FCVSR_PRECISION", "f32")
 cases = sys.argv[1:] or CASES
 for name in cases:
     x, gold, meta = load_case(name)
-    model = getattr(A, meta["ctor"])(**meta["kwargs"])
+    model = get_ctor(meta["ctor"])(**meta["kwargs"])
     model.load_state_dict(weights_for(meta), strict=True)
     model = model.to("cuda")
     with torch.no_grad():

@@ -56,6 +56,31 @@ def import_reference():
     return ref
 
 
+def import_reference_rgb():
+    """mmedit twins: loaded by file path with stub modules for mmcv / mmedit.models.registry."""
+    import importlib.util
+    sys.modules["cv2"].imwrite = lambda *a, **k: False
+    sys.modules.setdefault("mmcv", types.ModuleType("mmcv"))
+    reg = types.ModuleType("mmedit.models.registry")
+
+    class _Reg:
+        def register_module(self, *a, **k):
+            return lambda cls: cls
+
+    reg.BACKBONES = _Reg()
+    for name in ("mmedit", "mmedit.models"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["mmedit.models.registry"] = reg
+    mods = {}
+    base = "/root/reference/mmedit_train/mmedit/models/backbones/sr_backbones/"
+    for fn in ("fcvsr.py", "fcvsr_s.py"):
+        spec = importlib.util.spec_from_file_location("ref_" + fn[:-3], base + fn)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        mods[fn] = m
+    return mods
+
+
 def run_case(ref, name, ctor, kwargs, x, tap_filter=None):
     torch.manual_seed(0)
     model = getattr(ref, ctor)(**kwargs)
@@ -138,9 +163,16 @@ def main():
              np.random.RandomState(0).rand(1, 7, 1, 64, 64).astype(np.float32), ("out", "mgaa2.out"))
     run_case(ref, "Sreduced_24x16", "GShiftNet_S", dict(n_features=32, ACNum=2, Freq_Inv=2, SCGroupN=1),
              rs.rand(1, 7, 1, 24, 16).astype(np.float32), small)
+    rgb = import_reference_rgb()
+    sRS = run_case(rgb["fcvsr_s.py"], "rgbS_16x20", "FCVSR_SNet", {}, rs.rand(1, 7, 3, 16, 20).astype(np.float32),
+                   ("out", "mgaa2.out", "sc.o2", "fz", "feat"))
+    sRF = run_case(rgb["fcvsr.py"], "rgbfull_12x16", "FCVSRNet", {}, rs.rand(1, 7, 3, 12, 16).astype(np.float32),
+                   ("out", "mgaa2.out"))
     with open(os.path.join(HERE, "schema.json"), "w") as f:
         json.dump({"GShiftNet_S": {k: list(v) for k, v in sS.items()},
-                   "GShiftNet": {k: list(v) for k, v in sF.items()}}, f, indent=0)
+                   "GShiftNet": {k: list(v) for k, v in sF.items()},
+                   "FCVSR_SNet": {k: list(v) for k, v in sRS.items()},
+                   "FCVSRNet": {k: list(v) for k, v in sRF.items()}}, f, indent=0)
 
 
 if __name__ == "__main__":

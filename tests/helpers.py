@@ -8,7 +8,13 @@ import torch
 from fcvsr_amd.weights import synthetic_state_dict
 
 GOLDEN_DIR = os.path.join(os.path.dirname(__file__), "golden")
-CASES = ["S_16x20", "S_b2_72x36", "full_20x24", "S_cfg1_64x64", "Sreduced_24x16"]
+CASES = ["S_16x20", "S_b2_72x36", "full_20x24", "S_cfg1_64x64", "Sreduced_24x16", "rgbS_16x20", "rgbfull_12x16"]
+
+
+def get_ctor(name):
+    """Drop-in class by reference name: Y models (CVSR_train) or RGB twins (mmedit fork)."""
+    from fcvsr_amd.arch import CVSR_freq, fcvsr_rgb
+    return getattr(CVSR_freq, name) if hasattr(CVSR_freq, name) else getattr(fcvsr_rgb, name)
 
 
 def load_schema():

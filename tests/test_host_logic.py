@@ -13,7 +13,7 @@ from helpers import GOLDEN_DIR, load_schema
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-@pytest.mark.parametrize("ctor", ["GShiftNet_S", "GShiftNet"])
+@pytest.mark.parametrize("ctor", ["GShiftNet_S", "GShiftNet", "FCVSR_SNet", "FCVSRNet"])
 def test_state_dict_schema_matches_reference(ctor):
     from fcvsr_amd.arch.schema import state_dict_shapes
     ref = {k: tuple(v) for k, v in load_schema()[ctor].items()}
@@ -27,6 +27,17 @@ def test_param_counts_match_survey():
     assert sum(p.numel() for p in A.GShiftNet_S().parameters()) == 3704709
     with torch.device("meta"):
         assert sum(p.numel() for p in A.GShiftNet().parameters()) == 8811336
+
+
+def test_rgb_twin_param_counts_and_hooks():
+    from fcvsr_amd.arch import fcvsr_rgb as R
+    with torch.device("meta"):
+        assert sum(p.numel() for p in R.FCVSR_SNet().parameters()) == 4130951
+        assert sum(p.numel() for p in R.FCVSRNet().parameters()) == 8868938
+        m = R.FCVSR_SNet()
+    m.init_weights(None)
+    with pytest.raises(TypeError):
+        m.init_weights(123)
 
 
 def test_ctor_signature_defaults():

@@ -140,8 +140,19 @@ def main():
         all_fl = sum(r[2] for r in recs)
         peak = PEAK_TFLOPS[args.precision]
         ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        traffic = None
+        try:        # HBM bytes per launch from the committed PMC passes (same workload), see profiles/r01_pmc_traffic.json
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pm = json.load(f)
+            c = pm["config"]
+            if (c["model"], c["batch"], c["precision"], c["height"], c["width"]) == (args.model, B, args.precision, H, W) \
+                    and kind == "mfma":
+                traffic = round(pm["hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
+        alg_bytes = sum(r[5] for r in dom) / max(1, len(dom))
         roofline = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 5), "traffic": None,
+                    "frac": round(ach / peak, 5), "traffic": traffic, "algorithmic_bytes_per_launch": round(alg_bytes),
                     "kernel": "conv_direct_kernel" if kind == "direct" else "conv_mfma_kernel",
                     "launches_per_step": len(dom), "avg_launch_us": round(tot_ms * 1e3 / max(1, len(dom)), 2),
                     "flops_per_step_kernel": tot_fl, "flops_per_step_all_convs": all_fl,

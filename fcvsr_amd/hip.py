@@ -211,7 +211,8 @@ def conv2d_mfma(groups, wpacked: torch.Tensor, ksize: int, cout: int, mma_dtype:
         e0.record()
         check(lib().fcvsr_conv2d_mfma(descs, n, mma_dtype, stream_ptr()), "fcvsr_conv2d_mfma")
         e1.record()
-        PROFILE.append((e0, e1, flops, "mfma", name))
+        nbytes = sum(t.numel() * t.element_size() for g in groups for t in list(g["srcs"]) + list(g.get("res", ())) + [g["dst"]])
+        PROFILE.append((e0, e1, flops, "mfma", name, nbytes))
         return
     check(lib().fcvsr_conv2d_mfma(descs, n, mma_dtype, stream_ptr()), "fcvsr_conv2d_mfma")
 
@@ -232,7 +233,7 @@ def conv2d(srcs: Sequence[torch.Tensor], wpacked: torch.Tensor, ksize: int, cout
         e1.record()
         ho = (d.H + 2 * d.pad - d.kh) // stride + 1
         wo = (d.W + 2 * d.pad - d.kw) // stride + 1
-        PROFILE.append((e0, e1, 2.0 * d.B * ho * wo * cout * cin * ksize * ksize, "direct", name))
+        PROFILE.append((e0, e1, 2.0 * d.B * ho * wo * cout * cin * ksize * ksize, "direct", name, 0))
         return dst
     check(lib().fcvsr_conv2d(C.byref(d), stream_ptr()), "fcvsr_conv2d")
     return dst

@@ -220,8 +220,8 @@ __device__ __forceinline__ void epilogue_oct(const EpiCtx& e, float4 va, float4 
   *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.p) + o + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 
-template <bool BF16, int NT, int KS, int MW>
-__global__ __launch_bounds__(256, MW == 1 ? (NT == 128 ? 3 : 4) : 2) void conv_mfma_kernel(MfmaArgs a) {
+template <bool BF16, int NT, int KS, int MW, bool WD>
+__global__ __launch_bounds__(256, MW == 1 ? (WD ? (NT == 128 ? 2 : 3) : (NT == 128 ? 3 : 4)) : 2) void conv_mfma_kernel(MfmaArgs a) {
   constexpr int kTH = 4 * MW;                       // MW tile rows (M-fragments) per wave
   constexpr int PAD = KS / 2;
   constexpr int HH = kTH + 2 * PAD, HWD = kTW + 2 * PAD;
@@ -367,6 +367,50 @@ __global__ __launch_bounds__(256, MW == 1 ? (NT == 128 ? 3 : 4) : 2) void conv_m
         }
       }
     }
+    if (WD) {
+      // ---- weights straight from L2/L1 into the MFMA B-operand registers: no LDS staging, NO barriers in the tap loop.
+      // Lane (r,h) of N-fragment nf needs W[tap][n0+nf*32+r][c0+kk*16+h*8 .. +8]: one 16-byte load.  The flattened
+      // (tap,kk) sequence is software-pipelined PD steps ahead through a register ring; waves free-run through the taps.
+      constexpr int S = KS * KS * 4;
+      constexpr int PD = NT == 128 ? 3 : 4;
+      const long long wtap = (long long)a.cout_pad * a.cin_pad;
+      const long long wrow32 = 32ll * a.cin_pad;
+      const uint16_t* wl = a.w + ((long long)n0 + r) * a.cin_pad + c0 + h * 8;
+      uint4 bq[PD][NF];
+#pragma unroll
+      for (int s0 = 0; s0 < PD && s0 < S; ++s0) {
+        const int tap = s0 >> 2, kk = s0 & 3;
+        if (kk * 16 < ck && !(a.dbg & 8)) {
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf)
+            bq[s0][nf] = *reinterpret_cast<const uint4*>(wl + tap * wtap + nf * wrow32 + kk * 16);
+        }
+      }
+      __syncthreads();                     // A_s visible
+#pragma unroll
+      for (int s1 = 0; s1 < S; ++s1) {
+        const int tap = s1 >> 2, kk = s1 & 3;
+        const int ky = tap / KS, kx = tap - ky * KS;
+        if (kk * 16 < ck && !(a.dbg & 2)) {
+          const uint16_t* arow0 = A_s + ((MW * wave + ky) * HWD + r + kx) * kLD + h * 8;
+          uint4 af[MW];
+#pragma unroll
+          for (int m = 0; m < MW; ++m) af[m] = *reinterpret_cast<const uint4*>(arow0 + m * HWD * kLD + kk * 16);
+#pragma unroll
+          for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[m][nf] = mfma<BF16>(af[m], bq[s1 % PD][nf], acc[m][nf]);
+        }
+        if (s1 + PD < S) {
+          const int tap2 = (s1 + PD) >> 2, kk2 = (s1 + PD) & 3;
+          if (kk2 * 16 < ck && !(a.dbg & 8)) {
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+              bq[s1 % PD][nf] = *reinterpret_cast<const uint4*>(wl + tap2 * wtap + nf * wrow32 + kk2 * 16);
+          }
+        }
+      }
+    } else {
     // ---- taps: weights global -> regs -> LDS, then MFMA ---------------------------------------------------------------
     uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;   // named (not an array): must stay in VGPRs
     // weights for chunk columns beyond ck are never read by the MFMA loop (kk*16 < ck), but the 16-byte loads must stay
@@ -413,6 +457,7 @@ __global__ __launch_bounds__(256, MW == 1 ? (NT == 128 ? 3 : 4) : 2) void conv_m
             for (int nf = 0; nf < NF; ++nf) acc[m][nf] = mfma<BF16>(af[m], bf[nf], acc[m][nf]);
         }
       }
+    }
     }
   }
 
@@ -544,7 +589,336 @@ __global__ __launch_bounds__(256, MW == 1 ? (NT == 128 ? 3 : 4) : 2) void conv_m
   }
 }
 
-template <bool BF16, int NT, int KS, int MW>
+// =====================================================================================================================
+// Lean 3x3 kernel: the same algorithm as conv_mfma_kernel<.., KS=3, MW=1> specialised for the layers that carry the FLOPs
+// (one dense NHWC source, stride 1, no pixel shuffle, channel-contiguous destination, cin % 64 == 0).  PMC showed the generic
+// kernel is instruction-issue bound (1431 VALU + 1031 SALU instructions per wave for 72 MFMAs, SIMD issue 96 % busy):
+// here every per-element index computation is hoisted - halo staging walks (row, col) incrementally with 32-bit offsets and
+// constant LDS strides, the epilogue works on one tile row per wave with loop-invariant bias / channel offsets.
+// =====================================================================================================================
+template <bool BF16, int NT, bool SRC16, bool DST16>
+__global__ __launch_bounds__(256, NT == 128 ? 2 : 4) void conv3_lean_kernel(MfmaArgs a) {
+  constexpr int HWD = kTW + 2, NHP = 6 * HWD;          // 6 x 34 halo pixels
+  constexpr int NF = NT / 32;
+  constexpr int WLOADS = NT / 32;
+  extern __shared__ __align__(16) uint16_t lds[];
+  uint16_t* A_s = lds;
+  uint16_t* B_s = lds + NHP * kLD;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  int wid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = wid & 7, loc = wid >> 3;
+    wid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  }
+  const int nb = wid % a.n_nblk;
+  const int tflat = wid / a.n_nblk;
+  int gi = 0;
+  if (a.n_groups > 1 && tflat >= a.g[1].tile_begin) gi = 1;
+  if (a.n_groups > 2 && tflat >= a.g[2].tile_begin) gi = 2;
+  const MGroup& G = a.g[gi];
+  const int tl = tflat - G.tile_begin;
+  const int n0 = nb * NT;
+  const int per_img = G.tiles_x * G.tiles_y;
+  const int b = tl / per_img;
+  const int t2 = tl - b * per_img;
+  const int ty0 = (t2 / G.tiles_x) * 4, tx0 = (t2 % G.tiles_x) * kTW;
+  const int H = G.H, W = G.W;
+
+  f32x16_t acc[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nf][i] = 0.f;
+
+  // ---- staging geometry (per thread, loop invariant) ---------------------------------------------------------------
+  constexpr int EPL = SRC16 ? 8 : 4;                  // source elements per 16-byte load
+  constexpr int LPP = 64 / EPL;                       // lanes per halo pixel (64 channels per chunk)
+  constexpr int STEP = 256 / LPP;                     // halo pixels covered per iteration by the 256 threads
+  constexpr int ITERS = (NHP + STEP - 1) / STEP;
+  const int q = tid & (LPP - 1);
+  const int p0 = tid / LPP;                           // < STEP <= 32 < HWD: first pixel lies in halo row 0
+  const View sv = G.src[0];
+  const int ssx = (int)sv.sx, ssy = (int)sv.sy;
+  constexpr int ESZ = SRC16 ? 2 : 4;
+  const char* sbase = reinterpret_cast<const char*>(sv.p) + ((long long)b * sv.sb) * ESZ;
+  const int off0 = ((ty0 - 1) * ssy + (tx0 - 1 + p0) * ssx + q * EPL) * ESZ;      // byte offset of halo pixel p0
+  uint16_t* a_dst = A_s + p0 * kLD + q * EPL;
+
+  for (int c0 = 0; c0 < a.cin16; c0 += kCK) {
+    const int ck = (a.cin16 - c0) < kCK ? (a.cin16 - c0) : kCK;
+    __syncthreads();
+    {
+      int hy = 0, hx = p0, off = off0 + c0 * ESZ;
+      const bool cok = (c0 + q * EPL) < a.cin_total;
+      constexpr int SB = 7;                           // loads in flight per thread (register budget)
+#pragma unroll
+      for (int i0 = 0; i0 < ITERS; i0 += SB) {
+        uint4 v[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const int i = i0 + u;
+          v[u] = make_uint4(0, 0, 0, 0);
+          if (i < ITERS) {
+            const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+            const bool ok = cok && (p0 + i * STEP < NHP) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+            if (ok) v[u] = *reinterpret_cast<const uint4*>(sbase + (unsigned)off);
+            hx += STEP;
+            off += STEP * ssx * ESZ;
+            if (hx >= HWD) { hx -= HWD; ++hy; off += (ssy - HWD * ssx) * ESZ; }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const int i = i0 + u;
+          if (i < ITERS && p0 + i * STEP < NHP) {
+            if (SRC16) {
+              *reinterpret_cast<uint4*>(a_dst + i * STEP * kLD) = v[u];
+            } else {
+              const float4 f = __builtin_bit_cast(float4, v[u]);
+              *reinterpret_cast<uint2*>(a_dst + i * STEP * kLD) = cvt4<BF16>(f);
+            }
+          }
+        }
+      }
+    }
+    // ---- taps: weights global -> regs -> LDS (one tap ahead), MFMA ---------------------------------------------------
+    uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
+    const uint16_t* wbase = a.w + ((long long)n0 + (tid >> 3)) * a.cin_pad + c0 + (tid & 7) * 8;
+    const long long wtap = (long long)a.cout_pad * a.cin_pad;
+    const long long wrow32 = 32ll * a.cin_pad;
+#define FCVSR_FETCH_WL(TAP)                                                       \
+  do {                                                                            \
+    const uint16_t* wp_ = wbase + (TAP) * wtap;                                   \
+    w0 = *reinterpret_cast<const uint4*>(wp_);                                    \
+    if (WLOADS > 1) w1 = *reinterpret_cast<const uint4*>(wp_ + wrow32);           \
+    if (WLOADS > 2) w2 = *reinterpret_cast<const uint4*>(wp_ + 2 * wrow32);       \
+    if (WLOADS > 3) w3 = *reinterpret_cast<const uint4*>(wp_ + 3 * wrow32);       \
+  } while (0)
+    FCVSR_FETCH_WL(0);
+    uint16_t* bp = B_s + (tid >> 3) * kLD + (tid & 7) * 8;
+    const uint16_t* arow = A_s + (wave * HWD + r) * kLD + h * 8;
+    const uint16_t* brow = B_s + r * kLD + h * 8;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap > 0) __syncthreads();
+      *reinterpret_cast<uint4*>(bp) = w0;
+      if (WLOADS > 1) *reinterpret_cast<uint4*>(bp + 32 * kLD) = w1;
+      if (WLOADS > 2) *reinterpret_cast<uint4*>(bp + 64 * kLD) = w2;
+      if (WLOADS > 3) *reinterpret_cast<uint4*>(bp + 96 * kLD) = w3;
+      __syncthreads();
+      if (tap + 1 < 9) FCVSR_FETCH_WL(tap + 1);
+      const int ky = tap / 3, kx = tap % 3;            // compile-time after unrolling
+#pragma unroll
+      for (int kk = 0; kk < kCK / 16; ++kk) {
+        if (kk * 16 < ck) {
+          const uint4 af = *reinterpret_cast<const uint4*>(arow + (ky * HWD + kx) * kLD + kk * 16);
+          uint4 bf[NF];
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) bf[nf] = *reinterpret_cast<const uint4*>(brow + nf * 32 * kLD + kk * 16);
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) acc[nf] = mfma<BF16>(af, bf[nf], acc[nf]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: one tile row per wave ---------------------------------------------------------------------------------
+  float slope = a.slope;
+  if (a.act == FCVSR_ACT_PRELU) slope = a.slope_ptr[0];
+  const int act = a.act;
+  constexpr int EW = NT >= 64 ? 64 : 32;
+  constexpr int EROW = EW + 4;
+  __syncthreads();
+  float* E_s = reinterpret_cast<float*>(lds) + wave * (32 * EROW);
+  const int py = ty0 + wave;
+  const bool rowok = py < H;
+  const View dv = G.dst;
+  const View r0v = G.res[0], r1v = G.res[1];
+  const int dsx = (int)dv.sx, r0sx = (int)r0v.sx, r1sx = (int)r1v.sx;
+  const long long drow = (long long)b * dv.sb + (long long)py * dv.sy;
+  const float* r0row = r0v.p + (long long)b * r0v.sb + (long long)py * r0v.sy;
+  const float* r1row = r1v.p + (long long)b * r1v.sb + (long long)py * r1v.sy;
+  float gm = -INFINITY, gs = 0.f;
+  float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int nh = 0; nh < NT / EW; ++nh) {
+#pragma unroll
+    for (int nf2 = 0; nf2 < EW / 32; ++nf2) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        E_s[((i & 3) + 8 * (i >> 2) + 4 * h) * EROW + nf2 * 32 + r] = acc[nh * (EW / 32) + nf2][i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (DST16) {
+      // 8 couts per lane -> one 16-byte store; 8 lanes per pixel, 8 pixels per iteration
+      constexpr int OPR = EW / 8;
+      const int co = lane & (OPR - 1), psub = lane / OPR;
+      const int n = n0 + nh * EW + co * 8;
+      const bool nok = n < a.cout;
+      float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+      if (a.bias && nok) { b0 = *reinterpret_cast<const float4*>(a.bias + n); b1 = *reinterpret_cast<const float4*>(a.bias + n + 4); }
+      uint16_t* dp = reinterpret_cast<uint16_t*>(dv.p) + drow + n;
+      const float* es = E_s + psub * EROW + co * 8;
+      constexpr int PPI = 64 / OPR;                  // pixels per iteration
+#pragma unroll
+      for (int j = 0; j < 32 / PPI; ++j) {
+        const int px = tx0 + j * PPI + psub;
+        if (rowok && nok && px < W) {
+          const float4 va = *reinterpret_cast<const float4*>(es + j * PPI * EROW);
+          const float4 vb = *reinterpret_cast<const float4*>(es + j * PPI * EROW + 4);
+          float x[8] = {va.x + b0.x, va.y + b0.y, va.z + b0.z, va.w + b0.w, vb.x + b1.x, vb.y + b1.y, vb.z + b1.z, vb.w + b1.w};
+          if (act == FCVSR_ACT_RELU) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = fmaxf(x[k], 0.f);
+          } else if (act != FCVSR_ACT_NONE) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = x[k] >= 0.f ? x[k] : x[k] * slope;
+          }
+          if (a.n_res > 0) {
+            const float4 ra = *reinterpret_cast<const float4*>(r0row + px * r0sx + n), rb = *reinterpret_cast<const float4*>(r0row + px * r0sx + n + 4);
+            x[0] = fmaf(a.rs[0], ra.x, x[0]); x[1] = fmaf(a.rs[0], ra.y, x[1]); x[2] = fmaf(a.rs[0], ra.z, x[2]); x[3] = fmaf(a.rs[0], ra.w, x[3]);
+            x[4] = fmaf(a.rs[0], rb.x, x[4]); x[5] = fmaf(a.rs[0], rb.y, x[5]); x[6] = fmaf(a.rs[0], rb.z, x[6]); x[7] = fmaf(a.rs[0], rb.w, x[7]);
+          }
+          if (a.n_res > 1) {
+            const float4 ra = *reinterpret_cast<const float4*>(r1row + px * r1sx + n), rb = *reinterpret_cast<const float4*>(r1row + px * r1sx + n + 4);
+            x[0] = fmaf(a.rs[1], ra.x, x[0]); x[1] = fmaf(a.rs[1], ra.y, x[1]); x[2] = fmaf(a.rs[1], ra.z, x[2]); x[3] = fmaf(a.rs[1], ra.w, x[3]);
+            x[4] = fmaf(a.rs[1], rb.x, x[4]); x[5] = fmaf(a.rs[1], rb.y, x[5]); x[6] = fmaf(a.rs[1], rb.z, x[6]); x[7] = fmaf(a.rs[1], rb.w, x[7]);
+          }
+          const uint2 lo = cvt4<BF16>(make_float4(x[0], x[1], x[2], x[3])), hi = cvt4<BF16>(make_float4(x[4], x[5], x[6], x[7]));
+          *reinterpret_cast<uint4*>(dp + px * dsx) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+      }
+    } else {
+      constexpr int QPR = EW / 4;
+      const int cq = lane & (QPR - 1), psub = lane / QPR;
+      const int n = n0 + nh * EW + cq * 4;
+      const bool nok = n < a.cout;
+      float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.bias && nok) b0 = *reinterpret_cast<const float4*>(a.bias + n);
+      float4 wm = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.gc_wmask && nok) wm = *reinterpret_cast<const float4*>(a.gc_wmask + n);
+      float* dp = dv.p + drow + n;
+      const float* es = E_s + psub * EROW + cq * 4;
+      constexpr int PPI = 64 / QPR;
+#pragma unroll
+      for (int j = 0; j < 32 / PPI; ++j) {
+        const int px = tx0 + j * PPI + psub;
+        const bool pval = rowok && px < W;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pval && nok) {
+          const float4 va = *reinterpret_cast<const float4*>(es + j * PPI * EROW);
+          x = make_float4(va.x + b0.x, va.y + b0.y, va.z + b0.z, va.w + b0.w);
+          if (act == FCVSR_ACT_RELU) {
+            x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f);
+          } else if (act != FCVSR_ACT_NONE) {
+            x.x = x.x >= 0.f ? x.x : x.x * slope; x.y = x.y >= 0.f ? x.y : x.y * slope;
+            x.z = x.z >= 0.f ? x.z : x.z * slope; x.w = x.w >= 0.f ? x.w : x.w * slope;
+          }
+          if (a.n_res > 0) {
+            const float4 ra = *reinterpret_cast<const float4*>(r0row + px * r0sx + n);
+            x.x = fmaf(a.rs[0], ra.x, x.x); x.y = fmaf(a.rs[0], ra.y, x.y); x.z = fmaf(a.rs[0], ra.z, x.z); x.w = fmaf(a.rs[0], ra.w, x.w);
+          }
+          if (a.n_res > 1) {
+            const float4 ra = *reinterpret_cast<const float4*>(r1row + px * r1sx + n);
+            x.x = fmaf(a.rs[1], ra.x, x.x); x.y = fmaf(a.rs[1], ra.y, x.y); x.z = fmaf(a.rs[1], ra.z, x.z); x.w = fmaf(a.rs[1], ra.w, x.w);
+          }
+          *reinterpret_cast<float4*>(dp + px * dsx) = x;
+        }
+        if (a.gc_wmask) {
+          float part = x.x * wm.x + x.y * wm.y + x.z * wm.z + x.w * wm.w;     // x == 0 on invalid lanes
+#pragma unroll
+          for (int o = QPR / 2; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+          if (pval) {
+            const float mn = fmaxf(gm, part);
+            const float sc = expf(gm - mn), ee = expf(part - mn);
+            gs = gs * sc + ee;
+            ga.x = ga.x * sc + ee * x.x; ga.y = ga.y * sc + ee * x.y; ga.z = ga.z * sc + ee * x.z; ga.w = ga.w * sc + ee * x.w;
+            gm = mn;
+          }
+        }
+      }
+      if (a.gc_wmask && G.gc_partial) {
+#pragma unroll
+        for (int o = QPR; o < 64; o <<= 1) {
+          const float om = __shfl_xor(gm, o), os = __shfl_xor(gs, o);
+          const float ox = __shfl_xor(ga.x, o), oy = __shfl_xor(ga.y, o), oz = __shfl_xor(ga.z, o), ow = __shfl_xor(ga.w, o);
+          const float mn = fmaxf(gm, om);
+          const float s1 = (gm == -INFINITY) ? 0.f : expf(gm - mn), s2 = (om == -INFINITY) ? 0.f : expf(om - mn);
+          gs = gs * s1 + os * s2;
+          ga.x = ga.x * s1 + ox * s2; ga.y = ga.y * s1 + oy * s2; ga.z = ga.z * s1 + oz * s2; ga.w = ga.w * s1 + ow * s2;
+          gm = mn;
+        }
+        float* gw = reinterpret_cast<float*>(lds) + 4 * 32 * EROW + wave * (EW + 4);
+        if (lane < QPR) {
+          *reinterpret_cast<float4*>(gw + lane * 4) = ga;
+          if (lane == 0) { gw[EW] = gm; gw[EW + 1] = gs; }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!DST16 && a.gc_wmask && G.gc_partial && NT <= 64) {
+    constexpr int QPR = EW / 4;
+    __syncthreads();
+    if (wave == 0 && lane < QPR) {
+      const float* g0 = reinterpret_cast<const float*>(lds) + 4 * 32 * EROW;
+      float m = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) m = fmaxf(m, g0[w * (EW + 4) + EW]);
+      float sum = 0.f;
+      float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float mw = g0[w * (EW + 4) + EW];
+        const float sc = (mw == -INFINITY) ? 0.f : expf(mw - m);
+        sum = fmaf(g0[w * (EW + 4) + EW + 1], sc, sum);
+        const float4 v = *reinterpret_cast<const float4*>(g0 + w * (EW + 4) + lane * 4);
+        acc4.x = fmaf(v.x, sc, acc4.x); acc4.y = fmaf(v.y, sc, acc4.y); acc4.z = fmaf(v.z, sc, acc4.z); acc4.w = fmaf(v.w, sc, acc4.w);
+      }
+      float* pp = G.gc_partial + ((long long)b * per_img + t2) * (a.cout + 2);
+      const int n = lane * 4;
+      if (n < a.cout) pp[n] = acc4.x;
+      if (n + 1 < a.cout) pp[n + 1] = acc4.y;
+      if (n + 2 < a.cout) pp[n + 2] = acc4.z;
+      if (n + 3 < a.cout) pp[n + 3] = acc4.w;
+      if (lane == 0) { pp[a.cout] = m; pp[a.cout + 1] = sum; }
+    }
+  }
+}
+
+template <bool BF16, int NT, bool SRC16, bool DST16>
+static hipError_t launch_lean(const MfmaArgs& a, int total_tiles, hipStream_t st) {
+  size_t lds = ((size_t)6 * (kTW + 2) * kLD + (size_t)NT * kLD) * sizeof(uint16_t);
+  const size_t epi = (4ull * 32 + 4) * ((NT >= 64 ? 64 : 32) + 4) * sizeof(float);
+  if (lds < epi) lds = epi;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3_lean_kernel<BF16, NT, SRC16, DST16>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv3_lean_kernel<BF16, NT, SRC16, DST16>), dim3(total_tiles * a.n_nblk), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+template <bool BF16>
+static hipError_t dispatch_lean(const MfmaArgs& a, int nt, int total_tiles, hipStream_t st) {
+#define FCVSR_LEAN(NTV)                                                                                       \
+  (a.src16 ? (a.dst16 ? launch_lean<BF16, NTV, true, true>(a, total_tiles, st)                                  \
+                      : launch_lean<BF16, NTV, true, false>(a, total_tiles, st))                                \
+           : (a.dst16 ? launch_lean<BF16, NTV, false, true>(a, total_tiles, st)                                 \
+                      : launch_lean<BF16, NTV, false, false>(a, total_tiles, st)))
+  if (nt == 128) return FCVSR_LEAN(128);
+  if (nt == 64) return FCVSR_LEAN(64);
+  return FCVSR_LEAN(32);
+#undef FCVSR_LEAN
+}
+
+template <bool BF16, int NT, int KS, int MW, bool WD>
 static hipError_t launch_mfma(const MfmaArgs& a, int total_tiles, hipStream_t st) {
   constexpr int PAD = KS / 2;
   constexpr int kTH = 4 * MW;
@@ -553,30 +927,31 @@ static hipError_t launch_mfma(const MfmaArgs& a, int total_tiles, hipStream_t st
   if (lds < epi) lds = epi;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_mfma_kernel<BF16, NT, KS, MW>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_mfma_kernel<BF16, NT, KS, MW, WD>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_mfma_kernel<BF16, NT, KS, MW>), dim3(total_tiles * a.n_nblk), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<BF16, NT, KS, MW, WD>), dim3(total_tiles * a.n_nblk), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
-template <bool BF16, int MW>
+template <bool BF16, int MW, bool WD>
 static hipError_t dispatch2(const MfmaArgs& a, int nt, int ks, int total_tiles, hipStream_t st) {
   if (ks == 3) {
-    if (nt == 128) return launch_mfma<BF16, 128, 3, MW>(a, total_tiles, st);
-    if (nt == 64) return launch_mfma<BF16, 64, 3, MW>(a, total_tiles, st);
-    return launch_mfma<BF16, 32, 3, MW>(a, total_tiles, st);
+    if (nt == 128) return launch_mfma<BF16, 128, 3, MW, WD>(a, total_tiles, st);
+    if (nt == 64) return launch_mfma<BF16, 64, 3, MW, WD>(a, total_tiles, st);
+    return launch_mfma<BF16, 32, 3, MW, WD>(a, total_tiles, st);
   }
-  if (nt == 128) return launch_mfma<BF16, 128, 1, MW>(a, total_tiles, st);
-  if (nt == 64) return launch_mfma<BF16, 64, 1, MW>(a, total_tiles, st);
-  return launch_mfma<BF16, 32, 1, MW>(a, total_tiles, st);
+  if (nt == 128) return launch_mfma<BF16, 128, 1, MW, WD>(a, total_tiles, st);
+  if (nt == 64) return launch_mfma<BF16, 64, 1, MW, WD>(a, total_tiles, st);
+  return launch_mfma<BF16, 32, 1, MW, WD>(a, total_tiles, st);
 }
 
 template <bool BF16>
-static hipError_t dispatch(const MfmaArgs& a, int nt, int ks, int mw, int total_tiles, hipStream_t st) {
-  return mw == 1 ? dispatch2<BF16, 1>(a, nt, ks, total_tiles, st) : dispatch2<BF16, 2>(a, nt, ks, total_tiles, st);
+static hipError_t dispatch(const MfmaArgs& a, int nt, int ks, int mw, int wd, int total_tiles, hipStream_t st) {
+  if (mw == 2) return dispatch2<BF16, 2, false>(a, nt, ks, total_tiles, st);
+  return wd ? dispatch2<BF16, 1, true>(a, nt, ks, total_tiles, st) : dispatch2<BF16, 1, false>(a, nt, ks, total_tiles, st);
 }
 
 }  // namespace fcvsr
@@ -628,7 +1003,13 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   a.cin_pad = (cin + 63) / 64 * 64;   // packer pads cin to a multiple of 64 (16-byte weight loads stay in bounds)
   a.cout = d0.cout;
   a.cout_pad = d0.cout_pad;
-  const int nt = d0.cout > 64 ? 128 : (d0.cout > 32 ? 64 : 32);
+  // N tile: measured faster with <= 64 couts per workgroup (register pressure of 128-cout accumulators costs more than
+  // re-staging the input tile for the second N-block); FCVSR_MFMA_NTMAX=128 restores the wide tile for experiments.
+  int nt = d0.cout > 32 ? 64 : 32;
+  {
+    const char* e = getenv("FCVSR_MFMA_NTMAX");
+    if (e && atoi(e) == 128 && d0.cout > 64) nt = 128;
+  }
   a.n_nblk = (d0.cout + nt - 1) / nt;
   a.w = (const uint16_t*)d0.weight;
   a.bias = d0.bias;
@@ -653,6 +1034,11 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   {
     const char* e = getenv("FCVSR_MFMA_MW");
     if (e) mw = atoi(e) == 1 ? 1 : 2;
+  }
+  int wd = 0;     // weights straight from L2 into the B-operand registers (no LDS staging / tap barriers)
+  {
+    const char* e = getenv("FCVSR_MFMA_WD");
+    if (e) wd = atoi(e) ? 1 : 0;
   }
   const int kTH = 4 * mw;
   int tiles = 0;
@@ -699,7 +1085,25 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   }
   for (int g = n_groups; g < 3; ++g) a.g[g] = a.g[0];
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = (mma_dtype == FCVSR_BF16) ? dispatch<true>(a, nt, d0.kh, mw, tiles, st) : dispatch<false>(a, nt, d0.kh, mw, tiles, st);
+  // lean fast path: 3x3 stride 1, one dense source, cin multiple of 64, plain channel-contiguous destination and residuals
+  bool lean = d0.kh == 3 && d0.stride == 1 && mw == 1 && !wd && d0.n_src == 1 && !a.planar && !a.ps && (cin % 64 == 0) &&
+              (d0.cout % 8 == 0);
+  for (int g = 0; g < n_groups && lean; ++g) {
+    const fcvsr_conv_desc& d = descs[g];
+    lean = lean && d.dst.sc == 1 && (long long)d.B * d.H * d.W * (long long)(d.src[0].sx > d.dst.sx ? d.src[0].sx : d.dst.sx) < (1ll << 29);
+    for (int q = 0; q < d.n_res; ++q) lean = lean && d.res[q].sc == 1 && d.res[q].dtype == FCVSR_F32;
+  }
+  {
+    const char* e = getenv("FCVSR_MFMA_LEAN");
+    if (e && atoi(e) == 0) lean = false;
+  }
+  hipError_t e;
+  if (lean && nt > 64) {      // measured: two 64-cout workgroups per tile beat one 128-cout workgroup (register pressure)
+    nt = 64;
+    a.n_nblk = (d0.cout + nt - 1) / nt;
+  }
+  if (lean) e = (mma_dtype == FCVSR_BF16) ? dispatch_lean<true>(a, nt, tiles, st) : dispatch_lean<false>(a, nt, tiles, st);
+  else e = (mma_dtype == FCVSR_BF16) ? dispatch<true>(a, nt, d0.kh, mw, wd, tiles, st) : dispatch<false>(a, nt, d0.kh, mw, wd, tiles, st);
   if (e != hipSuccess) {
     set_error("fcvsr_conv2d_mfma: launch failed: %s", hipGetErrorString(e));
     return (int)e;

@@ -1,0 +1,13 @@
+import os, sys
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+import torch
+from fcvsr_amd import hip
+dt, mdt = torch.bfloat16, hip.BF16
+L3 = [(180, 320), (90, 160), (45, 80)]
+B, cin, cout = 8, 64, 64
+w = torch.randn(cout, cin, 3, 3, device="cuda") / 24
+wp = hip.pack_conv_weight_mfma(w, dt)
+groups = [dict(srcs=[torch.randn(B, H, W, cin, device="cuda")], dst=torch.empty(B, H, W, cout, device="cuda")) for H, W in L3]
+for _ in range(5):
+    hip.conv2d_mfma(groups, wp, 3, cout, mdt, act=hip.ACT_LEAKY, slope=0.1)
+torch.cuda.synchronize()

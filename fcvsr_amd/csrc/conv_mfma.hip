@@ -889,6 +889,212 @@ __global__ __launch_bounds__(256, NT == 128 ? 2 : 4) void conv3_lean_kernel(Mfma
   }
 }
 
+// Lean 1x1 kernel: flat list of pixels (128 per workgroup), up to 3 concatenated sources whose channel counts are
+// multiples of 64 (a 64-channel chunk never straddles two sources), optional pixel-shuffle destination (no residuals then).
+template <bool BF16, int NT, bool SRC16, bool DST16, bool PS>
+__global__ __launch_bounds__(256, 4) void conv1_lean_kernel(MfmaArgs a) {
+  constexpr int NPX = 128;
+  constexpr int NF = NT / 32;
+  constexpr int WLOADS = NT / 32;
+  extern __shared__ __align__(16) uint16_t lds[];
+  uint16_t* A_s = lds;
+  uint16_t* B_s = lds + NPX * kLD;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  int wid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = wid & 7, loc = wid >> 3;
+    wid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  }
+  const int nb = wid % a.n_nblk;
+  const int tflat = wid / a.n_nblk;
+  int gi = 0;
+  if (a.n_groups > 1 && tflat >= a.g[1].tile_begin) gi = 1;
+  if (a.n_groups > 2 && tflat >= a.g[2].tile_begin) gi = 2;
+  const MGroup& G = a.g[gi];
+  const int tl = tflat - G.tile_begin;
+  const int n0 = nb * NT;
+  const int npix = G.B * G.H * G.W;                   // host guarantees < 2^29
+  const int flat0 = tl * NPX;
+
+  f32x16_t acc[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nf][i] = 0.f;
+
+  constexpr int EPL = SRC16 ? 8 : 4;
+  constexpr int LPP = 64 / EPL;
+  constexpr int STEP = 256 / LPP;
+  constexpr int ITERS = NPX / STEP;
+  constexpr int ESZ = SRC16 ? 2 : 4;
+  const int q = tid & (LPP - 1);
+  const int p0 = tid / LPP;
+  uint16_t* a_dst = A_s + p0 * kLD + q * EPL;
+
+  for (int c0 = 0; c0 < a.cin16; c0 += kCK) {
+    // source segment of this chunk (uniform): segments are multiples of 64 channels
+    int sidx = 0, cl = c0;
+    if (cl >= a.seg_c[0]) { cl -= a.seg_c[0]; sidx = 1; if (cl >= a.seg_c[1]) { cl -= a.seg_c[1]; sidx = 2; } }
+    const View sv = G.src[sidx];
+    const char* sbase = reinterpret_cast<const char*>(sv.p) + (cl + q * EPL) * ESZ;
+    const int ssx = (int)sv.sx;
+    __syncthreads();
+    {
+      uint4 v[ITERS];
+#pragma unroll
+      for (int i = 0; i < ITERS; ++i) {
+        const int pix = flat0 + p0 + i * STEP;
+        v[i] = make_uint4(0, 0, 0, 0);
+        if (pix < npix) v[i] = *reinterpret_cast<const uint4*>(sbase + (size_t)((unsigned)pix * (unsigned)ssx) * ESZ);
+      }
+#pragma unroll
+      for (int i = 0; i < ITERS; ++i) {
+        if (SRC16) {
+          *reinterpret_cast<uint4*>(a_dst + i * STEP * kLD) = v[i];
+        } else {
+          *reinterpret_cast<uint2*>(a_dst + i * STEP * kLD) = cvt4<BF16>(__builtin_bit_cast(float4, v[i]));
+        }
+      }
+    }
+    {
+      const uint16_t* wp_ = a.w + ((long long)n0 + (tid >> 3)) * a.cin_pad + c0 + (tid & 7) * 8;
+      const long long wrow32 = 32ll * a.cin_pad;
+      uint16_t* bp = B_s + (tid >> 3) * kLD + (tid & 7) * 8;
+      const uint4 w0 = *reinterpret_cast<const uint4*>(wp_);
+      uint4 w1 = w0;
+      if (WLOADS > 1) w1 = *reinterpret_cast<const uint4*>(wp_ + wrow32);
+      *reinterpret_cast<uint4*>(bp) = w0;
+      if (WLOADS > 1) *reinterpret_cast<uint4*>(bp + 32 * kLD) = w1;
+    }
+    __syncthreads();
+    const uint16_t* arow = A_s + (wave * 32 + r) * kLD + h * 8;
+    const uint16_t* brow = B_s + r * kLD + h * 8;
+#pragma unroll
+    for (int kk = 0; kk < kCK / 16; ++kk) {
+      const uint4 af = *reinterpret_cast<const uint4*>(arow + kk * 16);
+      uint4 bf[NF];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) bf[nf] = *reinterpret_cast<const uint4*>(brow + nf * 32 * kLD + kk * 16);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) acc[nf] = mfma<BF16>(af, bf[nf], acc[nf]);
+    }
+  }
+
+  float slope = a.slope;
+  if (a.act == FCVSR_ACT_PRELU) slope = a.slope_ptr[0];
+  const int act = a.act;
+  constexpr int EW = NT >= 64 ? 64 : 32;
+  constexpr int EROW = EW + 4;
+  __syncthreads();
+  float* E_s = reinterpret_cast<float*>(lds) + wave * (32 * EROW);
+  const int rowpix = flat0 + wave * 32;
+  const View dv = G.dst;
+  const View r0v = G.res[0], r1v = G.res[1];
+  const int dsx = (int)dv.sx, r0sx = (int)r0v.sx, r1sx = (int)r1v.sx;
+  const int cq4 = a.cout >> 2;
+#pragma unroll
+  for (int nf2 = 0; nf2 < EW / 32; ++nf2) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) E_s[((i & 3) + 8 * (i >> 2) + 4 * h) * EROW + nf2 * 32 + r] = acc[nf2][i];
+  }
+  __builtin_amdgcn_wave_barrier();
+  constexpr int VPL = DST16 ? 8 : 4;                  // couts per lane
+  constexpr int LPR = EW / VPL;                       // lanes per pixel
+  constexpr int PPI = 64 / LPR;
+  const int co = lane & (LPR - 1), psub = lane / LPR;
+  const int n = n0 + co * VPL;
+  const bool nok = n < a.cout;
+  float bb[VPL];
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) bb[k] = 0.f;
+  if (a.bias && nok) {
+#pragma unroll
+    for (int k = 0; k < VPL; k += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(a.bias + n + k);
+      bb[k] = t.x; bb[k + 1] = t.y; bb[k + 2] = t.z; bb[k + 3] = t.w;
+    }
+  }
+  // pixel-shuffle: couts are sub-pixel-major, n = sp*(cout/4) + c
+  const int sp = PS ? n / cq4 : 0;
+  const int nn = PS ? n - sp * cq4 : n;
+  const float* es = E_s + psub * EROW + co * VPL;
+#pragma unroll
+  for (int j = 0; j < 32 / PPI; ++j) {
+    const int pix = rowpix + j * PPI + psub;
+    if (nok && pix < npix) {
+      float x[VPL];
+#pragma unroll
+      for (int k = 0; k < VPL; k += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(es + j * PPI * EROW + k);
+        x[k] = t.x + bb[k]; x[k + 1] = t.y + bb[k + 1]; x[k + 2] = t.z + bb[k + 2]; x[k + 3] = t.w + bb[k + 3];
+      }
+      if (act == FCVSR_ACT_RELU) {
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) x[k] = fmaxf(x[k], 0.f);
+      } else if (act != FCVSR_ACT_NONE) {
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) x[k] = x[k] >= 0.f ? x[k] : x[k] * slope;
+      }
+      if (!PS) {
+        if (a.n_res > 0) {
+#pragma unroll
+          for (int k = 0; k < VPL; k += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(r0v.p + (size_t)((unsigned)pix * (unsigned)r0sx) + n + k);
+            x[k] = fmaf(a.rs[0], t.x, x[k]); x[k + 1] = fmaf(a.rs[0], t.y, x[k + 1]);
+            x[k + 2] = fmaf(a.rs[0], t.z, x[k + 2]); x[k + 3] = fmaf(a.rs[0], t.w, x[k + 3]);
+          }
+        }
+        if (a.n_res > 1) {
+#pragma unroll
+          for (int k = 0; k < VPL; k += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(r1v.p + (size_t)((unsigned)pix * (unsigned)r1sx) + n + k);
+            x[k] = fmaf(a.rs[1], t.x, x[k]); x[k + 1] = fmaf(a.rs[1], t.y, x[k + 1]);
+            x[k + 2] = fmaf(a.rs[1], t.z, x[k + 2]); x[k + 3] = fmaf(a.rs[1], t.w, x[k + 3]);
+          }
+        }
+      }
+      size_t o;
+      if (PS) {
+        const int qx = pix % G.W, t1 = pix / G.W;
+        const int qy = t1 % G.H, qb = t1 / G.H;
+        o = (size_t)qb * dv.sb + (size_t)(2 * qy + (sp >> 1)) * dv.sy + (size_t)(2 * qx + (sp & 1)) * dsx + nn;
+      } else {
+        o = (size_t)((unsigned)pix * (unsigned)dsx) + n;
+      }
+      if (DST16) {
+        const uint2 lo = cvt4<BF16>(make_float4(x[0], x[1], x[2], x[3]));
+        const uint2 hi = cvt4<BF16>(make_float4(x[VPL - 4], x[VPL - 3], x[VPL - 2], x[VPL - 1]));
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(dv.p) + o) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      } else {
+        *reinterpret_cast<float4*>(dv.p + o) = make_float4(x[0], x[1], x[2], x[3]);
+      }
+    }
+  }
+}
+
+template <bool BF16, int NT, bool SRC16, bool DST16, bool PS>
+static hipError_t launch_lean1(const MfmaArgs& a, int total_tiles, hipStream_t st) {
+  size_t lds = ((size_t)128 * kLD + (size_t)NT * kLD) * sizeof(uint16_t);
+  const size_t epi = 4ull * 32 * ((NT >= 64 ? 64 : 32) + 4) * sizeof(float);
+  if (lds < epi) lds = epi;
+  hipLaunchKernelGGL((conv1_lean_kernel<BF16, NT, SRC16, DST16, PS>), dim3(total_tiles * a.n_nblk), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+template <bool BF16>
+static hipError_t dispatch_lean1(const MfmaArgs& a, int nt, int total_tiles, hipStream_t st) {
+#define FCVSR_L1(NTV, PSV)                                                                                      \
+  (a.src16 ? (a.dst16 ? launch_lean1<BF16, NTV, true, true, PSV>(a, total_tiles, st)                              \
+                      : launch_lean1<BF16, NTV, true, false, PSV>(a, total_tiles, st))                            \
+           : (a.dst16 ? launch_lean1<BF16, NTV, false, true, PSV>(a, total_tiles, st)                             \
+                      : launch_lean1<BF16, NTV, false, false, PSV>(a, total_tiles, st)))
+  if (a.ps) return nt == 64 ? FCVSR_L1(64, true) : FCVSR_L1(32, true);
+  return nt == 64 ? FCVSR_L1(64, false) : FCVSR_L1(32, false);
+#undef FCVSR_L1
+}
+
 template <bool BF16, int NT, bool SRC16, bool DST16>
 static hipError_t launch_lean(const MfmaArgs& a, int total_tiles, hipStream_t st) {
   size_t lds = ((size_t)6 * (kTW + 2) * kLD + (size_t)NT * kLD) * sizeof(uint16_t);
@@ -1097,7 +1303,32 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
     const char* e = getenv("FCVSR_MFMA_LEAN");
     if (e && atoi(e) == 0) lean = false;
   }
+  // lean 1x1 (flat) path: every source a multiple of 64 channels, channel-contiguous destination, f32 residuals;
+  // pixel shuffle only without residuals
+  bool lean1 = d0.kh == 1 && mw == 1 && !wd && nt <= 64 && (d0.cout % 8 == 0) && !a.planar;
+  for (int s2 = 0; s2 < d0.n_src && lean1; ++s2) lean1 = lean1 && (d0.src[s2].c % 64 == 0);
+  lean1 = lean1 && (!a.ps || (d0.n_res == 0 && (d0.cout / 4) % 8 == 0));
+  for (int g = 0; g < n_groups && lean1; ++g) {
+    const fcvsr_conv_desc& d = descs[g];
+    long long maxsx = d.dst.sx;
+    for (int s2 = 0; s2 < d.n_src; ++s2) maxsx = d.src[s2].sx > maxsx ? d.src[s2].sx : maxsx;
+    lean1 = lean1 && d.dst.sc == 1 && (long long)d.B * d.H * d.W * maxsx * 4 < (1ll << 31);
+    for (int q = 0; q < d.n_res; ++q)
+      lean1 = lean1 && d.res[q].sc == 1 && d.res[q].dtype == FCVSR_F32 && (long long)d.B * d.H * d.W * d.res[q].sx < (1ll << 31);
+  }
+  {
+    const char* e2 = getenv("FCVSR_MFMA_LEAN");
+    if (e2 && atoi(e2) == 0) lean1 = false;
+  }
   hipError_t e;
+  if (lean1) {
+    e = (mma_dtype == FCVSR_BF16) ? dispatch_lean1<true>(a, nt, tiles, st) : dispatch_lean1<false>(a, nt, tiles, st);
+    if (e != hipSuccess) {
+      set_error("fcvsr_conv2d_mfma: launch failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    return 0;
+  }
   if (lean && nt > 64) {      // measured: two 64-cout workgroups per tile beat one 128-cout workgroup (register pressure)
     nt = 64;
     a.n_nblk = (d0.cout + nt - 1) / nt;

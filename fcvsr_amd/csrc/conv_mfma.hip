@@ -796,8 +796,13 @@ __global__ __launch_bounds__(256, NT == 128 ? 2 : 4) void conv3_lean_kernel(Mfma
       const int cq = lane & (QPR - 1), psub = lane / QPR;
       const int n = n0 + nh * EW + cq * 4;
       const bool nok = n < a.cout;
+      const bool full = n + 3 < a.cout;                 // skinny layers (conv_last0: cout 1 or 3) take the scalar path
+      const bool vec = full && dv.sc == 1 && (a.n_res < 1 || r0v.sc == 1) && (a.n_res < 2 || r1v.sc == 1);
       float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a.bias && nok) b0 = *reinterpret_cast<const float4*>(a.bias + n);
+      if (a.bias && nok) {
+        if (full) b0 = *reinterpret_cast<const float4*>(a.bias + n);
+        else { b0.x = a.bias[n]; if (n + 1 < a.cout) b0.y = a.bias[n + 1]; if (n + 2 < a.cout) b0.z = a.bias[n + 2]; }
+      }
       float4 wm = make_float4(0.f, 0.f, 0.f, 0.f);
       if (a.gc_wmask && nok) wm = *reinterpret_cast<const float4*>(a.gc_wmask + n);
       float* dp = dv.p + drow + n;
@@ -817,15 +822,30 @@ __global__ __launch_bounds__(256, NT == 128 ? 2 : 4) void conv3_lean_kernel(Mfma
             x.x = x.x >= 0.f ? x.x : x.x * slope; x.y = x.y >= 0.f ? x.y : x.y * slope;
             x.z = x.z >= 0.f ? x.z : x.z * slope; x.w = x.w >= 0.f ? x.w : x.w * slope;
           }
-          if (a.n_res > 0) {
-            const float4 ra = *reinterpret_cast<const float4*>(r0row + px * r0sx + n);
-            x.x = fmaf(a.rs[0], ra.x, x.x); x.y = fmaf(a.rs[0], ra.y, x.y); x.z = fmaf(a.rs[0], ra.z, x.z); x.w = fmaf(a.rs[0], ra.w, x.w);
+          if (vec) {
+            if (a.n_res > 0) {
+              const float4 ra = *reinterpret_cast<const float4*>(r0row + px * r0sx + n);
+              x.x = fmaf(a.rs[0], ra.x, x.x); x.y = fmaf(a.rs[0], ra.y, x.y); x.z = fmaf(a.rs[0], ra.z, x.z); x.w = fmaf(a.rs[0], ra.w, x.w);
+            }
+            if (a.n_res > 1) {
+              const float4 ra = *reinterpret_cast<const float4*>(r1row + px * r1sx + n);
+              x.x = fmaf(a.rs[1], ra.x, x.x); x.y = fmaf(a.rs[1], ra.y, x.y); x.z = fmaf(a.rs[1], ra.z, x.z); x.w = fmaf(a.rs[1], ra.w, x.w);
+            }
+            *reinterpret_cast<float4*>(dp + px * dsx) = x;
+          } else {
+            float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (n + k < a.cout) {
+                if (a.n_res > 0) xs[k] = fmaf(a.rs[0], r0row[px * r0sx + (long long)(n + k) * r0v.sc], xs[k]);
+                if (a.n_res > 1) xs[k] = fmaf(a.rs[1], r1row[px * r1sx + (long long)(n + k) * r1v.sc], xs[k]);
+                dv.p[drow + px * dsx + (long long)(n + k) * dv.sc] = xs[k];
+              } else {
+                xs[k] = 0.f;
+              }
+            }
+            x = make_float4(xs[0], xs[1], xs[2], xs[3]);
           }
-          if (a.n_res > 1) {
-            const float4 ra = *reinterpret_cast<const float4*>(r1row + px * r1sx + n);
-            x.x = fmaf(a.rs[1], ra.x, x.x); x.y = fmaf(a.rs[1], ra.y, x.y); x.z = fmaf(a.rs[1], ra.z, x.z); x.w = fmaf(a.rs[1], ra.w, x.w);
-          }
-          *reinterpret_cast<float4*>(dp + px * dsx) = x;
         }
         if (a.gc_wmask) {
           float part = x.x * wm.x + x.y * wm.y + x.z * wm.z + x.w * wm.w;     // x == 0 on invalid lanes
@@ -1293,11 +1313,13 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   hipStream_t st = (hipStream_t)stream;
   // lean fast path: 3x3 stride 1, one dense source, cin multiple of 64, plain channel-contiguous destination and residuals
   bool lean = d0.kh == 3 && d0.stride == 1 && mw == 1 && !wd && d0.n_src == 1 && !a.planar && !a.ps && (cin % 64 == 0) &&
-              (d0.cout % 8 == 0);
+              (!a.dst16 || d0.cout % 8 == 0) && (d0.gc_wmask == nullptr || d0.cout % 4 == 0);
   for (int g = 0; g < n_groups && lean; ++g) {
     const fcvsr_conv_desc& d = descs[g];
-    lean = lean && d.dst.sc == 1 && (long long)d.B * d.H * d.W * (long long)(d.src[0].sx > d.dst.sx ? d.src[0].sx : d.dst.sx) < (1ll << 29);
-    for (int q = 0; q < d.n_res; ++q) lean = lean && d.res[q].sc == 1 && d.res[q].dtype == FCVSR_F32;
+    long long ext = (long long)d.B * d.H * d.W * (long long)(d.src[0].sx > d.dst.sx ? d.src[0].sx : d.dst.sx);
+    if (d.dst.sc != 1) ext = (long long)d.B * d.dst.sb;                 // strided (e.g. NCHW) destination
+    lean = lean && (!a.dst16 || d.dst.sc == 1) && ext < (1ll << 29);
+    for (int q = 0; q < d.n_res; ++q) lean = lean && d.res[q].dtype == FCVSR_F32 && (!a.dst16 || d.res[q].sc == 1);
   }
   {
     const char* e = getenv("FCVSR_MFMA_LEAN");

@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--precision", choices=["f32", "bf16", "f16"], default="bf16",
                     help="conv arithmetic: bf16/f16 MFMA operands with f32 accumulate (BASELINE config), or exact f32")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams the batch is split over")
+    ap.add_argument("--trunk16", type=int, default=0, help="1: SCNet trunk stored in the MFMA dtype (use with --precision f16)")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the forward from a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -91,6 +92,7 @@ def main():
     model.precision = args.precision
     model.streams = args.streams
     model.use_graph = bool(args.graph)
+    model.trunk16 = bool(args.trunk16)
     B, H, W = args.batch, args.height, args.width
     rs = np.random.RandomState(1 + rank)                      # different clips per rank, same weights
     x = torch.from_numpy(rs.rand(B, 7, 1, H, W).astype(np.float32)).to(dev)

@@ -191,6 +191,8 @@ class _GShiftBase(nn.Module):
         self.precision = os.environ.get("FCVSR_PRECISION", "f32")
         # number of HIP streams a batch is split over (independent clips; overlaps memory- and MFMA-bound phases)
         self.streams = int(os.environ.get("FCVSR_STREAMS", "1"))
+        # store the SCNetbk residual trunk in the MFMA dtype as well (16-bit modes only; use with precision="f16")
+        self.trunk16 = os.environ.get("FCVSR_TRUNK16", "0") == "1"
         # capture the launch sequence of a forward in a hipGraph (per input shape) and replay it
         self.use_graph = os.environ.get("FCVSR_GRAPH", "0") == "1"
 

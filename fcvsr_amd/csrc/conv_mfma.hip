@@ -56,6 +56,7 @@ struct MfmaArgs {
   int ps;
   int flat;            // 1x1: treat pixels as a flat list of B*H*W
   int src16, dst16;    // sources / destination stored in the MFMA dtype (16-bit) instead of f32
+  int res16;           // residual inputs stored in the MFMA dtype (lean 3x3 kernel only: 16-bit trunk)
   const float* gc_wmask;   // ContextBlock fusion: per-wave online-softmax partials of the output (cout <= 64, 3x3)
   int planar;          // single f32 source with arbitrary channel stride (the NCHW frames of feat_extract), cin <= 64
   int sub2;            // stride-2 convolution: evaluate at full resolution, keep the even output pixels only
@@ -596,6 +597,39 @@ __global__ __launch_bounds__(256, MW == 1 ? (WD ? (NT == 128 ? 2 : 3) : (NT == 1
 // here every per-element index computation is hoisted - halo staging walks (row, col) incrementally with 32-bit offsets and
 // constant LDS strides, the epilogue works on one tile row per wave with loop-invariant bias / channel offsets.
 // =====================================================================================================================
+template <bool BF16>
+__device__ __forceinline__ void cvt16x4_to_f32(uint2 v, float* o) {
+  if (BF16) {
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  } else {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    const h2 a = __builtin_bit_cast(h2, v.x), b = __builtin_bit_cast(h2, v.y);
+    o[0] = (float)a[0]; o[1] = (float)a[1]; o[2] = (float)b[0]; o[3] = (float)b[1];
+  }
+}
+
+// residual load of NV (4 or 8) consecutive channels at element offset `off` of a view base (f32 or 16-bit storage)
+template <bool BF16, int NV>
+__device__ __forceinline__ void load_res(const float* base, long long off, bool r16, float* o) {
+  if (r16) {
+    const uint16_t* p = reinterpret_cast<const uint16_t*>(base) + off;
+    if (NV == 8) {
+      const uint4 v = *reinterpret_cast<const uint4*>(p);
+      cvt16x4_to_f32<BF16>(make_uint2(v.x, v.y), o);
+      cvt16x4_to_f32<BF16>(make_uint2(v.z, v.w), o + 4);
+    } else {
+      cvt16x4_to_f32<BF16>(*reinterpret_cast<const uint2*>(p), o);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NV; k += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(base + off + k);
+      o[k] = t.x; o[k + 1] = t.y; o[k + 2] = t.z; o[k + 3] = t.w;
+    }
+  }
+}
+
 template <bool BF16, int NT, bool SRC16, bool DST16>
 __global__ __launch_bounds__(256, NT == 128 ? 2 : 4) void conv3_lean_kernel(MfmaArgs a) {
   constexpr int HWD = kTW + 2, NHP = 6 * HWD;          // 6 x 34 halo pixels
@@ -739,8 +773,9 @@ __global__ __launch_bounds__(256, NT == 128 ? 2 : 4) void conv3_lean_kernel(Mfma
   const View r0v = G.res[0], r1v = G.res[1];
   const int dsx = (int)dv.sx, r0sx = (int)r0v.sx, r1sx = (int)r1v.sx;
   const long long drow = (long long)b * dv.sb + (long long)py * dv.sy;
-  const float* r0row = r0v.p + (long long)b * r0v.sb + (long long)py * r0v.sy;
-  const float* r1row = r1v.p + (long long)b * r1v.sb + (long long)py * r1v.sy;
+  const long long r0off = (long long)b * r0v.sb + (long long)py * r0v.sy;
+  const long long r1off = (long long)b * r1v.sb + (long long)py * r1v.sy;
+  const bool r16 = a.res16 != 0;
   float gm = -INFINITY, gs = 0.f;
   float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -778,14 +813,16 @@ __global__ __launch_bounds__(256, NT == 128 ? 2 : 4) void conv3_lean_kernel(Mfma
             for (int k = 0; k < 8; ++k) x[k] = x[k] >= 0.f ? x[k] : x[k] * slope;
           }
           if (a.n_res > 0) {
-            const float4 ra = *reinterpret_cast<const float4*>(r0row + px * r0sx + n), rb = *reinterpret_cast<const float4*>(r0row + px * r0sx + n + 4);
-            x[0] = fmaf(a.rs[0], ra.x, x[0]); x[1] = fmaf(a.rs[0], ra.y, x[1]); x[2] = fmaf(a.rs[0], ra.z, x[2]); x[3] = fmaf(a.rs[0], ra.w, x[3]);
-            x[4] = fmaf(a.rs[0], rb.x, x[4]); x[5] = fmaf(a.rs[0], rb.y, x[5]); x[6] = fmaf(a.rs[0], rb.z, x[6]); x[7] = fmaf(a.rs[0], rb.w, x[7]);
+            float rr[8];
+            load_res<BF16, 8>(r0v.p, r0off + px * r0sx + n, r16, rr);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = fmaf(a.rs[0], rr[k], x[k]);
           }
           if (a.n_res > 1) {
-            const float4 ra = *reinterpret_cast<const float4*>(r1row + px * r1sx + n), rb = *reinterpret_cast<const float4*>(r1row + px * r1sx + n + 4);
-            x[0] = fmaf(a.rs[1], ra.x, x[0]); x[1] = fmaf(a.rs[1], ra.y, x[1]); x[2] = fmaf(a.rs[1], ra.z, x[2]); x[3] = fmaf(a.rs[1], ra.w, x[3]);
-            x[4] = fmaf(a.rs[1], rb.x, x[4]); x[5] = fmaf(a.rs[1], rb.y, x[5]); x[6] = fmaf(a.rs[1], rb.z, x[6]); x[7] = fmaf(a.rs[1], rb.w, x[7]);
+            float rr[8];
+            load_res<BF16, 8>(r1v.p, r1off + px * r1sx + n, r16, rr);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = fmaf(a.rs[1], rr[k], x[k]);
           }
           const uint2 lo = cvt4<BF16>(make_float4(x[0], x[1], x[2], x[3])), hi = cvt4<BF16>(make_float4(x[4], x[5], x[6], x[7]));
           *reinterpret_cast<uint4*>(dp + px * dsx) = make_uint4(lo.x, lo.y, hi.x, hi.y);
@@ -824,12 +861,14 @@ __global__ __launch_bounds__(256, NT == 128 ? 2 : 4) void conv3_lean_kernel(Mfma
           }
           if (vec) {
             if (a.n_res > 0) {
-              const float4 ra = *reinterpret_cast<const float4*>(r0row + px * r0sx + n);
-              x.x = fmaf(a.rs[0], ra.x, x.x); x.y = fmaf(a.rs[0], ra.y, x.y); x.z = fmaf(a.rs[0], ra.z, x.z); x.w = fmaf(a.rs[0], ra.w, x.w);
+              float rr[4];
+              load_res<BF16, 4>(r0v.p, r0off + px * r0sx + n, r16, rr);
+              x.x = fmaf(a.rs[0], rr[0], x.x); x.y = fmaf(a.rs[0], rr[1], x.y); x.z = fmaf(a.rs[0], rr[2], x.z); x.w = fmaf(a.rs[0], rr[3], x.w);
             }
             if (a.n_res > 1) {
-              const float4 ra = *reinterpret_cast<const float4*>(r1row + px * r1sx + n);
-              x.x = fmaf(a.rs[1], ra.x, x.x); x.y = fmaf(a.rs[1], ra.y, x.y); x.z = fmaf(a.rs[1], ra.z, x.z); x.w = fmaf(a.rs[1], ra.w, x.w);
+              float rr[4];
+              load_res<BF16, 4>(r1v.p, r1off + px * r1sx + n, r16, rr);
+              x.x = fmaf(a.rs[1], rr[0], x.x); x.y = fmaf(a.rs[1], rr[1], x.y); x.z = fmaf(a.rs[1], rr[2], x.z); x.w = fmaf(a.rs[1], rr[3], x.w);
             }
             *reinterpret_cast<float4*>(dp + px * dsx) = x;
           } else {
@@ -837,8 +876,8 @@ __global__ __launch_bounds__(256, NT == 128 ? 2 : 4) void conv3_lean_kernel(Mfma
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               if (n + k < a.cout) {
-                if (a.n_res > 0) xs[k] = fmaf(a.rs[0], r0row[px * r0sx + (long long)(n + k) * r0v.sc], xs[k]);
-                if (a.n_res > 1) xs[k] = fmaf(a.rs[1], r1row[px * r1sx + (long long)(n + k) * r1v.sc], xs[k]);
+                if (a.n_res > 0) xs[k] = fmaf(a.rs[0], r0v.p[r0off + px * r0sx + (long long)(n + k) * r0v.sc], xs[k]);
+                if (a.n_res > 1) xs[k] = fmaf(a.rs[1], r1v.p[r1off + px * r1sx + (long long)(n + k) * r1v.sc], xs[k]);
                 dv.p[drow + px * dsx + (long long)(n + k) * dv.sc] = xs[k];
               } else {
                 xs[k] = 0.f;
@@ -1211,6 +1250,7 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   FCVSR_CHECK_ARG(!d0.pixel_shuffle || d0.cout % 16 == 0, "pixel_shuffle needs cout%16==0 (sub-pixel-major packing)");
   MfmaArgs a;
   a.src16 = d0.src[0].dtype != FCVSR_F32;
+  a.res16 = (d0.n_res > 0 && d0.res[0].dtype != FCVSR_F32) ? 1 : 0;
   a.sub2 = d0.stride == 2;
   a.planar = (d0.n_src == 1 && d0.src[0].sc != 1) ? 1 : 0;
   FCVSR_CHECK_ARG(!a.planar || (d0.src[0].dtype == FCVSR_F32 && d0.src[0].c <= 32 && d0.kh == 3),
@@ -1285,7 +1325,9 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
         FCVSR_CHECK_ARG(d.src[s].sy == d.src[s].sx * d.W && d.src[s].sb == d.src[s].sy * d.H, "1x1 needs uniformly strided pixels");
     }
     for (int q = 0; q < d.n_res; ++q) {
-      FCVSR_CHECK_ARG(d.res[q].ptr && d.res[q].dtype == FCVSR_F32 && vec_view_ok(d.res[q]), "res must be f32, 16-byte aligned");
+      FCVSR_CHECK_ARG(d.res[q].ptr && (d.res[q].dtype == FCVSR_F32 || d.res[q].dtype == mma_dtype) &&
+                          d.res[q].dtype == d0.res[0].dtype && vec_view_ok(d.res[q]),
+                      "res must be f32 or the MFMA dtype (all alike), vector-aligned");
       G.res[q] = to_view(d.res[q]);
       if (a.flat)
         FCVSR_CHECK_ARG(d.res[q].sy == d.res[q].sx * d.W && d.res[q].sb == d.res[q].sy * d.H, "1x1 needs uniformly strided res");
@@ -1319,8 +1361,10 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
     long long ext = (long long)d.B * d.H * d.W * (long long)(d.src[0].sx > d.dst.sx ? d.src[0].sx : d.dst.sx);
     if (d.dst.sc != 1) ext = (long long)d.B * d.dst.sb;                 // strided (e.g. NCHW) destination
     lean = lean && (!a.dst16 || d.dst.sc == 1) && ext < (1ll << 29);
-    for (int q = 0; q < d.n_res; ++q) lean = lean && d.res[q].dtype == FCVSR_F32 && (!a.dst16 || d.res[q].sc == 1);
+    for (int q = 0; q < d.n_res; ++q)
+      lean = lean && (d.res[q].dtype == FCVSR_F32 || d.res[q].sc == 1) && (!a.dst16 || d.res[q].sc == 1);
   }
+  FCVSR_CHECK_ARG(!a.res16 || lean, "16-bit residuals are only supported by the lean 3x3 path");
   {
     const char* e = getenv("FCVSR_MFMA_LEAN");
     if (e && atoi(e) == 0) lean = false;

@@ -56,7 +56,8 @@ __global__ void divenh_apply_kernel(DivEnhExprF ex, float* s_f, float* s_o, cons
   else { s_f[t] += fv; s_o[t] += o; }
 }
 
-__global__ void scale_add_kernel(const float4* z, const float* gate, const float4* x, float4* out, long long HWCq, int Cq,
+template <int DT>
+__global__ void scale_add_kernel(const float4* z, const float* gate, const float4* x, void* out, long long HWCq, int Cq,
                                  long long total) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
@@ -64,7 +65,18 @@ __global__ void scale_add_kernel(const float4* z, const float* gate, const float
   const int cq = (int)(t % Cq);
   const float* g = gate + (long long)b * Cq * 4 + cq * 4;
   const float4 zz = z[t], xx = x[t];
-  out[t] = make_float4(fmaf(zz.x, g[0], xx.x), fmaf(zz.y, g[1], xx.y), fmaf(zz.z, g[2], xx.z), fmaf(zz.w, g[3], xx.w));
+  const float4 o = make_float4(fmaf(zz.x, g[0], xx.x), fmaf(zz.y, g[1], xx.y), fmaf(zz.z, g[2], xx.z), fmaf(zz.w, g[3], xx.w));
+  if (DT == FCVSR_F32) {
+    reinterpret_cast<float4*>(out)[t] = o;
+  } else if (DT == FCVSR_BF16) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 b4;
+    const b4 c = {(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
+    reinterpret_cast<uint2*>(out)[t] = __builtin_bit_cast(uint2, c);
+  } else {
+    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+    const h4 c = {(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
+    reinterpret_cast<uint2*>(out)[t] = __builtin_bit_cast(uint2, c);
+  }
 }
 
 }  // namespace fcvsr
@@ -96,16 +108,24 @@ extern "C" int fcvsr_divenh(int mode, int first, const float* f, float* s_f, flo
   return 0;
 }
 
-extern "C" int fcvsr_scale_add(const float* z, const float* gate, const float* x, float* out, int B, int H, int W, int C,
-                               void* stream) {
+extern "C" int fcvsr_scale_add(const float* z, const float* gate, const float* x, void* out, int out_dtype, int B, int H,
+                               int W, int C, void* stream) {
   FCVSR_CHECK_ARG(z && gate && x && out, "null pointer");
   FCVSR_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "C%4==0 required");
   FCVSR_CHECK_ARG(((uintptr_t)z % 16 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0), "16-byte alignment");
   const int Cq = C / 4;
   const long long HWCq = (long long)H * W * Cq;
   const long long total = HWCq * B;
-  hipLaunchKernelGGL(scale_add_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)z, gate,
-                     (const float4*)x, (float4*)out, HWCq, Cq, total);
+  FCVSR_CHECK_ARG(out_dtype == FCVSR_F32 || out_dtype == FCVSR_BF16 || out_dtype == FCVSR_F16, "bad out_dtype");
+  if (out_dtype == FCVSR_F32)
+    hipLaunchKernelGGL((scale_add_kernel<FCVSR_F32>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)z,
+                       gate, (const float4*)x, out, HWCq, Cq, total);
+  else if (out_dtype == FCVSR_BF16)
+    hipLaunchKernelGGL((scale_add_kernel<FCVSR_BF16>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)z,
+                       gate, (const float4*)x, out, HWCq, Cq, total);
+  else
+    hipLaunchKernelGGL((scale_add_kernel<FCVSR_F16>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)z,
+                       gate, (const float4*)x, out, HWCq, Cq, total);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

@@ -127,18 +127,47 @@ __global__ void gc_stage2_kernel(const float* part, int nblk, int C, const float
   }
 }
 
-__global__ void gc_apply_kernel(const float4* r, const float* add, const float4* z, float4* out, float slope,
+// ---- 16-bit activation storage (trunk16 mode): 4 channels = 8 bytes ---------------------------------------------------
+template <int DT>
+__device__ __forceinline__ float4 ld4(const void* base, long long quad) {
+  if (DT == FCVSR_F32) return reinterpret_cast<const float4*>(base)[quad];
+  const uint2 v = reinterpret_cast<const uint2*>(base)[quad];
+  if (DT == FCVSR_BF16)
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  const h2 a = __builtin_bit_cast(h2, v.x), b = __builtin_bit_cast(h2, v.y);
+  return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+}
+
+template <int DT>
+__device__ __forceinline__ void st4(void* base, long long quad, float4 x) {
+  if (DT == FCVSR_F32) {
+    reinterpret_cast<float4*>(base)[quad] = x;
+  } else if (DT == FCVSR_BF16) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 b4;
+    const b4 c = {(__bf16)x.x, (__bf16)x.y, (__bf16)x.z, (__bf16)x.w};
+    reinterpret_cast<uint2*>(base)[quad] = __builtin_bit_cast(uint2, c);
+  } else {
+    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+    const h4 c = {(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w};
+    reinterpret_cast<uint2*>(base)[quad] = __builtin_bit_cast(uint2, c);
+  }
+}
+
+template <int DT>
+__global__ void gc_apply_kernel(const float4* r, const float* add, const void* z, void* out, float slope,
                                 long long HWCq, int Cq, long long total) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   const int b = (int)(t / HWCq);
   const int cq = (int)(t % Cq);
   const float* a = add + (long long)b * Cq * 4 + cq * 4;
-  const float4 rr = r[t], zz = z[t];
+  const float4 rr = r[t], zz = ld4<DT>(z, t);
   float4 v = make_float4(rr.x + a[0], rr.y + a[1], rr.z + a[2], rr.w + a[3]);
   v.x = v.x >= 0.f ? v.x : v.x * slope; v.y = v.y >= 0.f ? v.y : v.y * slope;
   v.z = v.z >= 0.f ? v.z : v.z * slope; v.w = v.w >= 0.f ? v.w : v.w * slope;
-  out[t] = make_float4(v.x + zz.x, v.y + zz.y, v.z + zz.z, v.w + zz.w);
+  st4<DT>(out, t, make_float4(v.x + zz.x, v.y + zz.y, v.z + zz.z, v.w + zz.w));
 }
 
 __device__ __forceinline__ float4 f4_axpy(float a, float4 x, float4 y) {
@@ -146,7 +175,8 @@ __device__ __forceinline__ float4 f4_axpy(float a, float4 x, float4 y) {
 }
 
 // out = x + rs*r + mean2x2(dn) + bilinear_x2(up)   (F.interpolate align_corners=False semantics)
-__global__ void xscale_kernel(const float4* x, const float4* r, float rs, const float4* dn, const float4* up, float4* out,
+template <int DT>
+__global__ void xscale_kernel(const void* x, const void* r, float rs, const void* dn, const void* up, void* out,
                               int B, int H, int W, int Cq) {
   const long long total = (long long)B * H * W * Cq;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -156,14 +186,14 @@ __global__ void xscale_kernel(const float4* x, const float4* r, float rs, const 
   const int xx = (int)(pg % W);
   const int yy = (int)((pg / W) % H);
   const int b = (int)(pg / ((long long)W * H));
-  float4 acc = f4_axpy(rs, r[t], x[t]);
+  float4 acc = f4_axpy(rs, ld4<DT>(r, t), ld4<DT>(x, t));
   if (dn) {
     const int H2 = 2 * H, W2 = 2 * W;
-    const float4* d = dn + ((long long)b * H2 * W2) * Cq + cq;
-    const float4 a00 = d[((long long)(2 * yy) * W2 + 2 * xx) * Cq];
-    const float4 a01 = d[((long long)(2 * yy) * W2 + 2 * xx + 1) * Cq];
-    const float4 a10 = d[((long long)(2 * yy + 1) * W2 + 2 * xx) * Cq];
-    const float4 a11 = d[((long long)(2 * yy + 1) * W2 + 2 * xx + 1) * Cq];
+    const long long d0 = ((long long)b * H2 * W2) * Cq + cq;
+    const float4 a00 = ld4<DT>(dn, d0 + ((long long)(2 * yy) * W2 + 2 * xx) * Cq);
+    const float4 a01 = ld4<DT>(dn, d0 + ((long long)(2 * yy) * W2 + 2 * xx + 1) * Cq);
+    const float4 a10 = ld4<DT>(dn, d0 + ((long long)(2 * yy + 1) * W2 + 2 * xx) * Cq);
+    const float4 a11 = ld4<DT>(dn, d0 + ((long long)(2 * yy + 1) * W2 + 2 * xx + 1) * Cq);
     // torch upsample_bilinear2d order: lerp along x inside each row, then along y (weights 0.5)
     const float4 top = make_float4(0.5f * a00.x + 0.5f * a01.x, 0.5f * a00.y + 0.5f * a01.y, 0.5f * a00.z + 0.5f * a01.z,
                                    0.5f * a00.w + 0.5f * a01.w);
@@ -179,16 +209,16 @@ __global__ void xscale_kernel(const float4* x, const float4* r, float rs, const 
     const int y0 = (int)sy, x0 = (int)sx;
     const int y1 = y0 + (y0 < Hh - 1 ? 1 : 0), x1 = x0 + (x0 < Wh - 1 ? 1 : 0);
     const float ly = sy - (float)y0, lx = sx - (float)x0;
-    const float4* u = up + ((long long)b * Hh * Wh) * Cq + cq;
-    const float4 u00 = u[((long long)y0 * Wh + x0) * Cq], u01 = u[((long long)y0 * Wh + x1) * Cq];
-    const float4 u10 = u[((long long)y1 * Wh + x0) * Cq], u11 = u[((long long)y1 * Wh + x1) * Cq];
+    const long long u0 = ((long long)b * Hh * Wh) * Cq + cq;
+    const float4 u00 = ld4<DT>(up, u0 + ((long long)y0 * Wh + x0) * Cq), u01 = ld4<DT>(up, u0 + ((long long)y0 * Wh + x1) * Cq);
+    const float4 u10 = ld4<DT>(up, u0 + ((long long)y1 * Wh + x0) * Cq), u11 = ld4<DT>(up, u0 + ((long long)y1 * Wh + x1) * Cq);
     const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
     acc = f4_axpy(w00, u00, acc);
     acc = f4_axpy(w01, u01, acc);
     acc = f4_axpy(w10, u10, acc);
     acc = f4_axpy(w11, u11, acc);
   }
-  out[t] = acc;
+  st4<DT>(out, t, acc);
 }
 
 }  // namespace fcvsr
@@ -226,29 +256,45 @@ extern "C" int fcvsr_gc_finish(const float* partial, int nparts, const float* w1
   return 0;
 }
 
-extern "C" int fcvsr_gc_apply(const float* r, const float* add, const float* z, float* out, float slope, int B, int H,
-                              int W, int C, void* stream) {
+extern "C" int fcvsr_gc_apply(const float* r, const float* add, const void* z, void* out, int io_dtype, float slope, int B,
+                              int H, int W, int C, void* stream) {
   FCVSR_CHECK_ARG(r && add && z && out, "null pointer");
   FCVSR_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "C%4==0 required");
   FCVSR_CHECK_ARG(al16(r) && al16(z) && al16(out), "16-byte alignment");
   const int Cq = C / 4;
   const long long HWCq = (long long)H * W * Cq;
   const long long total = HWCq * B;
-  hipLaunchKernelGGL(gc_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)r, add,
-                     (const float4*)z, (float4*)out, slope, HWCq, Cq, total);
+  FCVSR_CHECK_ARG(io_dtype == FCVSR_F32 || io_dtype == FCVSR_BF16 || io_dtype == FCVSR_F16, "bad io_dtype");
+  if (io_dtype == FCVSR_F32)
+    hipLaunchKernelGGL((gc_apply_kernel<FCVSR_F32>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)r,
+                       add, z, out, slope, HWCq, Cq, total);
+  else if (io_dtype == FCVSR_BF16)
+    hipLaunchKernelGGL((gc_apply_kernel<FCVSR_BF16>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)r,
+                       add, z, out, slope, HWCq, Cq, total);
+  else
+    hipLaunchKernelGGL((gc_apply_kernel<FCVSR_F16>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)r,
+                       add, z, out, slope, HWCq, Cq, total);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int fcvsr_xscale(const float* x, const float* r, float r_scale, const float* dn, const float* up, float* out,
-                            int B, int H, int W, int C, void* stream) {
+extern "C" int fcvsr_xscale(const void* x, const void* r, float r_scale, const void* dn, const void* up, void* out,
+                            int io_dtype, int B, int H, int W, int C, void* stream) {
   FCVSR_CHECK_ARG(x && r && out, "null pointer");
   FCVSR_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "C%4==0 required");
   FCVSR_CHECK_ARG(!up || (H % 2 == 0 && W % 2 == 0), "up source needs even H,W");
   FCVSR_CHECK_ARG(al16(x) && al16(r) && al16(out) && al16(dn) && al16(up), "16-byte alignment");
   const long long total = (long long)B * H * W * (C / 4);
-  hipLaunchKernelGGL(xscale_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
-                     (const float4*)r, r_scale, (const float4*)dn, (const float4*)up, (float4*)out, B, H, W, C / 4);
+  FCVSR_CHECK_ARG(io_dtype == FCVSR_F32 || io_dtype == FCVSR_BF16 || io_dtype == FCVSR_F16, "bad io_dtype");
+  if (io_dtype == FCVSR_F32)
+    hipLaunchKernelGGL((xscale_kernel<FCVSR_F32>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, r, r_scale, dn,
+                       up, out, B, H, W, C / 4);
+  else if (io_dtype == FCVSR_BF16)
+    hipLaunchKernelGGL((xscale_kernel<FCVSR_BF16>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, r, r_scale, dn,
+                       up, out, B, H, W, C / 4);
+  else
+    hipLaunchKernelGGL((xscale_kernel<FCVSR_F16>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, r, r_scale, dn,
+                       up, out, B, H, W, C / 4);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

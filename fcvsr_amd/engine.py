@@ -119,6 +119,18 @@ class Engine:
             self._packed[key] = (pk, b, w.shape[0], w.shape[-1])
         return self._packed[key]
 
+    def _tdt(self):
+        """Storage dtype of the SCNetbk trunk (x, t2, R, cross-scale terms, block outputs): f32, or - with
+        model.trunk16 in the 16-bit modes - the MFMA operand dtype (halves the bytes and the staging instructions of
+        every SCNet kernel; f16 recommended: each block rounds the trunk once)."""
+        if self.precision == "f32" or not getattr(self._model(), "trunk16", False):
+            return torch.float32
+        return self._adt()
+
+    @staticmethod
+    def _code(dt):
+        return {torch.float32: hip.F32, torch.bfloat16: hip.BF16, torch.float16: hip.F16}[dt]
+
     def _adt(self, freq=False):
         """Storage dtype for tensors whose only consumers are MFMA convolutions: the MFMA operand dtype itself
         (the consumer would round to it anyway, so results are bit-identical and the HBM bytes halve)."""
@@ -301,7 +313,7 @@ class Engine:
         return out
 
     # ---------------------------------------------------------------------------------------------- MFFR
-    def _mffr(self, x):
+    def _mffr(self, x, out_dtype=torch.float32):
         """MultiFreq_Refinment.forward (CVSR_freq.py:2201-2254) on dense NHWC x."""
         m = self._model()
         n, Q = m.n_feats, m.Freq_Inv
@@ -342,12 +354,12 @@ class Engine:
                                  b.data_ptr(), mean_sum.data_ptr(), inv_hw, g1.data_ptr(), ptr(g2), None, None, 0,
                                  B, H, W, n, st), "fcvsr_divenh(apply)")
         g = self._ca_gate(self._channel_sum(s_o), inv_hw, "MFFRblock.ca", B, n)
-        out = self._new(dev, B, H, W, n)
-        check(L.fcvsr_scale_add(s_o.data_ptr(), g.data_ptr(), x.data_ptr(), out.data_ptr(), B, H, W, n, st),
-              "fcvsr_scale_add")
+        out = self._new(dev, B, H, W, n, dtype=out_dtype)
+        check(L.fcvsr_scale_add(s_o.data_ptr(), g.data_ptr(), x.data_ptr(), out.data_ptr(), self._code(out_dtype), B, H, W,
+                                n, st), "fcvsr_scale_add")
         if self.taps is not None:
             self.taps["mffr.bands"] = torch.stack([f.permute(0, 3, 1, 2) for f in freq], 1).contiguous().clone()
-            self._tap("mffr.out", out)
+            self._tap("mffr.out", out.float())
         return out
 
     # ---------------------------------------------------------------------------------------------- SCNetbk
@@ -363,7 +375,8 @@ class Engine:
 
         # the four 3x3 convs of the block run once per layer over all three pyramid levels (shared weights, one launch)
         t1 = [like(x, 2 * n, self._adt()) for x in xs]      # consumed only by the next conv -> MFMA operand dtype
-        t2 = [like(x, n) for x in xs]
+        tdt = self._tdt()
+        t2 = [like(x, n, tdt) for x in xs]
         r1 = [like(x, n, self._adt()) for x in xs]
         rr = [like(x, n) for x in xs]
         self._convg(pre + ".body.0", [dict(srcs=[x], dst=t) for x, t in zip(xs, t1)], act=ACT_LEAKY, slope=0.1)
@@ -390,9 +403,9 @@ class Engine:
                 scratch = self._new(dev, B * nblk * (n + 2))
                 check(L.fcvsr_gc_context(r.data_ptr(), wmask.data_ptr(), w1g.data_ptr(), w2g.data_ptr(), B, H, W, n,
                                          add.data_ptr(), scratch.data_ptr(), scratch.numel(), st), "fcvsr_gc_context")
-            Rl = self._new(dev, B, H, W, n)
-            check(L.fcvsr_gc_apply(r.data_ptr(), add.data_ptr(), t2[l].data_ptr(), Rl.data_ptr(), 0.2, B, H, W, n, st),
-                  "fcvsr_gc_apply")
+            Rl = self._new(dev, B, H, W, n, dtype=tdt)
+            check(L.fcvsr_gc_apply(r.data_ptr(), add.data_ptr(), t2[l].data_ptr(), Rl.data_ptr(), self._code(tdt), 0.2, B,
+                                   H, W, n, st), "fcvsr_gc_apply")
             R.append(Rl)
         dn = [torch.empty_like(R[l]) for l in (0, 1)]
         up = [torch.empty_like(R[l]) for l in (1, 2)]
@@ -405,8 +418,8 @@ class Engine:
             rs = 2.0 if l in (0, 2) else 1.0
             d = dn[l - 1] if l >= 1 else None
             u = up[l] if l <= 1 else None
-            check(L.fcvsr_xscale(x.data_ptr(), R[l].data_ptr(), rs, ptr(d), ptr(u), y.data_ptr(), B, H, W, n, st),
-                  "fcvsr_xscale")
+            check(L.fcvsr_xscale(x.data_ptr(), R[l].data_ptr(), rs, ptr(d), ptr(u), y.data_ptr(), self._code(tdt), B, H, W,
+                                 n, st), "fcvsr_xscale")
             outs.append(y)
         return outs
 
@@ -418,7 +431,8 @@ class Engine:
             for k in range(3):
                 t = self._block_rcb(f"recorb1.body.{g}.body.{k}", t)
             last = g == m.SCGroupN - 1
-            nxt = [torch.empty_like(c) for c in cur]
+            # the trunk may be 16-bit (trunk16); SCNetbk's outputs leave in f32
+            nxt = [torch.empty_like(c, dtype=torch.float32 if last else c.dtype) for c in cur]
             # fold SCNetbk's outer skip (x + body(x), :817-821) into the last group conv's epilogue
             grp = [dict(srcs=[t[l]], dst=nxt[l], res=([cur[l], xs[l]] if last else [cur[l]])) for l in range(3)]
             self._convg(f"recorb1.body.{g}.conv", grp)
@@ -508,9 +522,10 @@ class Engine:
         a1 = self._mgaa(f1[..., :n], f1[..., n:2 * n], f1[..., 2 * n:], "1")
         a3 = self._mgaa(f3[..., :n], f3[..., n:2 * n], f3[..., 2 * n:], "3")
         a2 = self._mgaa(a1, f2, a3, "2")
-        d0 = self._mffr(a2)
-        d1 = self._new(dev, B, H // 2, W // 2, n)
-        d2 = self._new(dev, B, H // 4, W // 4, n)
+        tdt = self._tdt()
+        d0 = self._mffr(a2, out_dtype=tdt)
+        d1 = self._new(dev, B, H // 2, W // 2, n, dtype=tdt)
+        d2 = self._new(dev, B, H // 4, W // 4, n, dtype=tdt)
         self._conv("rconcat1", [d0], d1, stride=2)
         self._conv("rconcat2", [d1], d2, stride=2)
         o0, o1, o2 = self._scnet([d0, d1, d2])

@@ -139,8 +139,8 @@ int fcvsr_iac_step(const fcvsr_view* prev, const fcvsr_view* off, const fcvsr_vi
 int fcvsr_divenh(int mode, int first, const float* f, float* s_f, float* s_o, const float* a, const float* b,
                  const float* mean_f_sum, float inv_hw, const float* g1, const float* g2,
                  float* sums, float* scratch, int64_t scratch_elems, int B, int H, int W, int C, void* stream);
-/* out = z*gate[b][c] + x   (final CALayer of MFFR, :2229-2230) */
-int fcvsr_scale_add(const float* z, const float* gate, const float* x, float* out, int B, int H, int W, int C,
+/* out = z*gate[b][c] + x   (final CALayer of MFFR, :2229-2230); out stored as out_dtype */
+int fcvsr_scale_add(const float* z, const float* gate, const float* x, void* out, int out_dtype, int B, int H, int W, int C,
                     void* stream);
 
 /* ---- SCNetbk pieces (CVSR_freq.py:657-822) ------------------------------------------------------------------- */
@@ -151,12 +151,12 @@ int fcvsr_gc_context(const float* r, const float* wmask, const float* w1, const 
 /* second half of fcvsr_gc_context for partials produced by the fused conv epilogue (or any producer of the same layout) */
 int fcvsr_gc_finish(const float* partial, int nparts, const float* w1, const float* w2, int B, int C, float* add,
                     void* stream);
-/* RCB tail (:722-725): out = lrelu0.2(r + add[b][c]) + z */
-int fcvsr_gc_apply(const float* r, const float* add, const float* z, float* out, float slope,
+/* RCB tail (:722-725): out = lrelu0.2(r + add[b][c]) + z; r is f32, z and out are f32 or 16-bit (io_dtype: trunk16 mode) */
+int fcvsr_gc_apply(const float* r, const float* add, const void* z, void* out, int io_dtype, float slope,
                    int B, int H, int W, int C, void* stream);
 /* BlockRCB cross-scale sum (:766-777): out = x + r_scale*r + avgpool2(dn) + bilinear_up2(up); dn/up may be NULL.
- * dn is (B,2H,2W,C), up is (B,H/2,W/2,C) */
-int fcvsr_xscale(const float* x, const float* r, float r_scale, const float* dn, const float* up, float* out,
+ * dn is (B,2H,2W,C), up is (B,H/2,W/2,C); all tensors f32 or all 16-bit (io_dtype) */
+int fcvsr_xscale(const void* x, const void* r, float r_scale, const void* dn, const void* up, void* out, int io_dtype,
                  int B, int H, int W, int C, void* stream);
 
 /* ---- tail ------------------------------------------------------------------------------------------------------ */

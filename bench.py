@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--precision", choices=["f32", "bf16", "f16"], default="bf16",
                     help="conv arithmetic: bf16/f16 MFMA operands with f32 accumulate (BASELINE config), or exact f32")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams the batch is split over")
-    ap.add_argument("--trunk16", type=int, default=0, help="1: SCNet trunk stored in the MFMA dtype (use with --precision f16)")
+    ap.add_argument("--trunk16", type=int, default=1, help="1: spatial activations / SCNet trunk stored in the MFMA dtype")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the forward from a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -185,7 +185,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"FCVSR-{args.model} 4x inference, {B}x7x{H}x{W} -> {4*H}x{4*W} synthetic clips, "
-                                   f"random-init (key-seeded) weights", "batch_per_gpu": B, "streams_per_gpu": args.streams, "hipgraph": bool(args.graph),
+                                   f"random-init (key-seeded) weights", "batch_per_gpu": B, "streams_per_gpu": args.streams, "hipgraph": bool(args.graph), "act16": bool(args.trunk16),
                        "parallelism": f"clip-dp{world}"},
             "frames_per_sec_per_gpu": round(fps / world, 3),
             "conv_tflops_end_to_end": round(fps * conv_flops_live(args.model, H, W) / 1e12, 3),

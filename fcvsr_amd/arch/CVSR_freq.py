@@ -191,8 +191,10 @@ class _GShiftBase(nn.Module):
         self.precision = os.environ.get("FCVSR_PRECISION", "f32")
         # number of HIP streams a batch is split over (independent clips; overlaps memory- and MFMA-bound phases)
         self.streams = int(os.environ.get("FCVSR_STREAMS", "1"))
-        # store the SCNetbk residual trunk in the MFMA dtype as well (16-bit modes only; use with precision="f16")
-        self.trunk16 = os.environ.get("FCVSR_TRUNK16", "0") == "1"
+        # 16-bit modes only: store the spatial activations (extracted features, aligned features, SCNetbk trunk) in the
+        # MFMA dtype instead of f32 - half the HBM bytes and staging instructions.  Spectra, offsets, MultiFreq_Refinment
+        # internals, ContextBlock statistics and all accumulation stay f32.
+        self.trunk16 = os.environ.get("FCVSR_TRUNK16", "1") == "1"
         # capture the launch sequence of a forward in a hipGraph (per input shape) and replay it
         self.use_graph = os.environ.get("FCVSR_GRAPH", "0") == "1"
 

@@ -180,7 +180,14 @@ __device__ __forceinline__ int run_stages(float* lds, const FftPlan& plan, int L
 }
 
 // ---- forward rows: real (B,H,W,n) -> half spectrum, two channels per complex lane -------------------------------
-__global__ __launch_bounds__(512) void rfft_rows_kernel(View src, int n, int H, int W, int L, float* spec,
+__device__ __forceinline__ float ld_act(const float* base, long long idx, int dt) {
+  if (dt == FCVSR_F32) return base[idx];
+  const unsigned short u = reinterpret_cast<const unsigned short*>(base)[idx];
+  if (dt == FCVSR_BF16) return __uint_as_float((unsigned)u << 16);
+  return (float)__builtin_bit_cast(_Float16, u);
+}
+
+__global__ __launch_bounds__(512) void rfft_rows_kernel(View src, int src_dt, int n, int H, int W, int L, float* spec,
                                                         long long ps, int im_off, int re_off, FftPlan plan) {
   extern __shared__ __align__(16) float lds[];
   const int NL = W * L;
@@ -188,13 +195,13 @@ __global__ __launch_bounds__(512) void rfft_rows_kernel(View src, int n, int H, 
   const int c0 = blockIdx.x * 2 * L;   // channel chunks of one row are dispatched together (they share 128-byte lines)
   const int Wf = W / 2 + 1;
   make_twiddles(lds + 4 * NL, W, false);
-  const float* sp = src.p + (long long)b * src.sb + (long long)y * src.sy;
+  const long long sp = (long long)b * src.sb + (long long)y * src.sy;
   for (int t = threadIdx.x; t < NL; t += blockDim.x) {
     const int l = t & (L - 1), x = t >> (31 - __clz(L));
     const int ca = c0 + l, cb = c0 + L + l;
-    const float* px = sp + (long long)x * src.sx;
-    lds[t] = ca < n ? px[(long long)ca * src.sc] : 0.f;
-    lds[NL + t] = cb < n ? px[(long long)cb * src.sc] : 0.f;
+    const long long px = sp + (long long)x * src.sx;
+    lds[t] = ca < n ? ld_act(src.p, px + (long long)ca * src.sc, src_dt) : 0.f;
+    lds[NL + t] = cb < n ? ld_act(src.p, px + (long long)cb * src.sc, src_dt) : 0.f;
   }
   __syncthreads();
   const int cur = run_stages<false>(lds, plan, L);
@@ -313,7 +320,7 @@ using namespace fcvsr;
 extern "C" int fcvsr_rfft2(const fcvsr_view* src, int B, int H, int W, int n, float* spec, int64_t pix_stride,
                            int im_off, int re_off, void* stream) {
   FCVSR_CHECK_ARG(src && src->ptr && spec, "null pointer");
-  FCVSR_CHECK_ARG(src->dtype == FCVSR_F32, "f32 only");
+  FCVSR_CHECK_ARG(src->dtype == FCVSR_F32 || src->dtype == FCVSR_BF16 || src->dtype == FCVSR_F16, "bad src dtype");
   FCVSR_CHECK_ARG(B > 0 && H > 0 && W > 1 && n > 0 && n <= src->c, "bad sizes");
   FftPlan pw, ph;
   FCVSR_CHECK_ARG(make_plan(W, &pw) && make_plan(H, &ph), "length has too many factors");
@@ -325,7 +332,7 @@ extern "C" int fcvsr_rfft2(const fcvsr_view* src, int B, int H, int W, int n, fl
     const size_t lds = 16ull * W * L + 8ull * W;
     (void)allow_lds(rfft_rows_kernel, lds);
     dim3 grid(cdiv(n, 2 * L), B * H);
-    hipLaunchKernelGGL(rfft_rows_kernel, grid, dim3(512), lds, st, to_view(*src), n, H, W, L, spec,
+    hipLaunchKernelGGL(rfft_rows_kernel, grid, dim3(512), lds, st, to_view(*src), (int)src->dtype, n, H, W, L, spec,
                        (long long)pix_stride, im_off, re_off, pw);
     FCVSR_LAUNCH_CHECK();
   }

@@ -46,7 +46,35 @@ __device__ __forceinline__ void load_k12(const void* base, long long elem_off, f
   }
 }
 
-template <int KDT>
+// feature tensors (prev, feat_in, dst) are f32 or 16-bit (ADT); 4 channels per lane
+template <int ADT>
+__device__ __forceinline__ float4 ld_f4(const float* base, long long elem) {
+  if (ADT == FCVSR_F32) return *reinterpret_cast<const float4*>(base + elem);
+  const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem);
+  if (ADT == FCVSR_BF16)
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  const h2 a = __builtin_bit_cast(h2, v.x), b = __builtin_bit_cast(h2, v.y);
+  return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+}
+
+template <int ADT>
+__device__ __forceinline__ void st_f4(float* base, long long elem, float4 x) {
+  if (ADT == FCVSR_F32) {
+    *reinterpret_cast<float4*>(base + elem) = x;
+  } else if (ADT == FCVSR_BF16) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 b4;
+    const b4 c = {(__bf16)x.x, (__bf16)x.y, (__bf16)x.z, (__bf16)x.w};
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + elem) = __builtin_bit_cast(uint2, c);
+  } else {
+    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+    const h4 c = {(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w};
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + elem) = __builtin_bit_cast(uint2, c);
+  }
+}
+
+template <int KDT, int ADT>
 __global__ __launch_bounds__(256) void iac_step_kernel(View prev, View off, View k1, View fin, float slope, int B, int H,
                                                        int W, View dst, int tiles_x, int tiles_y) {
   __shared__ __align__(16) float s_s[kIHY * kIHX * kIC];
@@ -60,7 +88,7 @@ __global__ __launch_bounds__(256) void iac_step_kernel(View prev, View off, View
   const int ty0 = (t2 / tiles_x) * kIY, tx0 = (t2 % tiles_x) * kIX;
 
   // ---- phase 1: s = flow_warp(prev, off) on the halo tile (coordinates clamped = replicate padding of s) -------------
-  const float* pp = prev.p + (long long)b * prev.sb + c0;
+  const long long pp = (long long)b * prev.sb + c0;
   for (int hp = tid >> 3; hp < kIHY * kIHX; hp += 32) {
     const int hy = hp / kIHX, hx = hp - hy * kIHX;
     int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
@@ -82,7 +110,7 @@ __global__ __launch_bounds__(256) void iac_step_kernel(View prev, View off, View
         const int xi = x0 + dx, yi = y0 + dy;
         if (xi >= 0 && xi < W && yi >= 0 && yi < H) {
           const float w = (dy ? wy1 : wy0) * (dx ? wx1 : wx0);
-          const float4 v = *reinterpret_cast<const float4*>(pp + (long long)yi * prev.sy + (long long)xi * prev.sx);
+          const float4 v = ld_f4<ADT>(prev.p, pp + (long long)yi * prev.sy + (long long)xi * prev.sx);
           acc.x = fmaf(v.x, w, acc.x); acc.y = fmaf(v.y, w, acc.y);
           acc.z = fmaf(v.z, w, acc.z); acc.w = fmaf(v.w, w, acc.w);
         }
@@ -125,12 +153,11 @@ __global__ __launch_bounds__(256) void iac_step_kernel(View prev, View off, View
         acc.x = fmaf(v.x, k[0][tt], acc.x); acc.y = fmaf(v.y, k[1][tt], acc.y);
         acc.z = fmaf(v.z, k[2][tt], acc.z); acc.w = fmaf(v.w, k[3][tt], acc.w);
       }
-      const float4 f = *reinterpret_cast<const float4*>(fin.p + (long long)b * fin.sb + (long long)gy * fin.sy +
-                                                        (long long)gx * fin.sx + c0);
+      const float4 f = ld_f4<ADT>(fin.p, (long long)b * fin.sb + (long long)gy * fin.sy + (long long)gx * fin.sx + c0);
       acc.x += f.x; acc.y += f.y; acc.z += f.z; acc.w += f.w;
       acc.x = acc.x >= 0.f ? acc.x : acc.x * slope; acc.y = acc.y >= 0.f ? acc.y : acc.y * slope;
       acc.z = acc.z >= 0.f ? acc.z : acc.z * slope; acc.w = acc.w >= 0.f ? acc.w : acc.w * slope;
-      *reinterpret_cast<float4*>(dst.p + (long long)b * dst.sb + (long long)gy * dst.sy + (long long)gx * dst.sx + c0) = acc;
+      st_f4<ADT>(dst.p, (long long)b * dst.sb + (long long)gy * dst.sy + (long long)gx * dst.sx + c0, acc);
     }
   }
 }
@@ -139,11 +166,31 @@ __global__ __launch_bounds__(256) void iac_step_kernel(View prev, View off, View
 
 using namespace fcvsr;
 
-static bool quad_ok(const fcvsr_view* v) { return v && v->ptr && v->dtype == FCVSR_F32 && vec4_ok(*v); }
+static bool quad_ok(const fcvsr_view* v, int dt) {
+  if (!v || !v->ptr || v->dtype != dt || v->sc != 1 || v->c % 4) return false;
+  const int g = dt == FCVSR_F32 ? 4 : 4;       // 4-channel accesses: 16 bytes (f32) / 8 bytes (16-bit)
+  const int al = dt == FCVSR_F32 ? 16 : 8;
+  return v->sx % g == 0 && v->sy % g == 0 && v->sb % g == 0 && ((uintptr_t)v->ptr % al) == 0;
+}
+
+template <int KDT>
+static void launch_iac(int adt, dim3 grid, hipStream_t st, View pv, View ov, View kv, View fv, float slope, int B, int H, int W,
+                       View dv, int tx, int ty) {
+  if (adt == FCVSR_F32)
+    hipLaunchKernelGGL((iac_step_kernel<KDT, FCVSR_F32>), grid, dim3(256), 0, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
+  else if (adt == FCVSR_BF16)
+    hipLaunchKernelGGL((iac_step_kernel<KDT, FCVSR_BF16>), grid, dim3(256), 0, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
+  else
+    hipLaunchKernelGGL((iac_step_kernel<KDT, FCVSR_F16>), grid, dim3(256), 0, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
+}
 
 extern "C" int fcvsr_iac_step(const fcvsr_view* prev, const fcvsr_view* off, const fcvsr_view* k1, const fcvsr_view* feat_in,
                               float slope, int B, int H, int W, const fcvsr_view* dst, void* stream) {
-  FCVSR_CHECK_ARG(quad_ok(prev) && quad_ok(feat_in) && quad_ok(dst), "prev/feat_in/dst: f32, channel-contiguous, aligned");
+  FCVSR_CHECK_ARG(prev && prev->ptr, "null prev");
+  const int adt = prev->dtype;
+  FCVSR_CHECK_ARG(adt == FCVSR_F32 || adt == FCVSR_BF16 || adt == FCVSR_F16, "bad feature dtype");
+  FCVSR_CHECK_ARG(quad_ok(prev, adt) && quad_ok(feat_in, adt) && quad_ok(dst, adt),
+                  "prev/feat_in/dst: same dtype, channel-contiguous, aligned");
   FCVSR_CHECK_ARG(off && off->ptr && off->c >= 2 && off->dtype == FCVSR_F32, "off needs 2 f32 channels");
   FCVSR_CHECK_ARG(k1 && k1->ptr && k1->sc == 1 && k1->c == 3 * prev->c, "k1 must have 3*C contiguous channels");
   FCVSR_CHECK_ARG(prev->c % kIC == 0 && prev->c == dst->c && prev->c == feat_in->c, "C must be a multiple of 32");
@@ -153,16 +200,10 @@ extern "C" int fcvsr_iac_step(const fcvsr_view* prev, const fcvsr_view* off, con
   const int tx = cdiv(W, kIX), ty = cdiv(H, kIY);
   dim3 grid(B * tx * ty, prev->c / kIC);
   hipStream_t st = (hipStream_t)stream;
-  View kv = to_view(*k1);
-  if (k1->dtype == FCVSR_F32)
-    hipLaunchKernelGGL((iac_step_kernel<FCVSR_F32>), grid, dim3(256), 0, st, to_view(*prev), to_view(*off), kv,
-                       to_view(*feat_in), slope, B, H, W, to_view(*dst), tx, ty);
-  else if (k1->dtype == FCVSR_BF16)
-    hipLaunchKernelGGL((iac_step_kernel<FCVSR_BF16>), grid, dim3(256), 0, st, to_view(*prev), to_view(*off), kv,
-                       to_view(*feat_in), slope, B, H, W, to_view(*dst), tx, ty);
-  else
-    hipLaunchKernelGGL((iac_step_kernel<FCVSR_F16>), grid, dim3(256), 0, st, to_view(*prev), to_view(*off), kv,
-                       to_view(*feat_in), slope, B, H, W, to_view(*dst), tx, ty);
+  const View pv = to_view(*prev), ov = to_view(*off), kv = to_view(*k1), fv = to_view(*feat_in), dv = to_view(*dst);
+  if (k1->dtype == FCVSR_F32) launch_iac<FCVSR_F32>(adt, grid, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
+  else if (k1->dtype == FCVSR_BF16) launch_iac<FCVSR_BF16>(adt, grid, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
+  else launch_iac<FCVSR_F16>(adt, grid, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

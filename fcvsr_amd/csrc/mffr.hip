@@ -56,15 +56,27 @@ __global__ void divenh_apply_kernel(DivEnhExprF ex, float* s_f, float* s_o, cons
   else { s_f[t] += fv; s_o[t] += o; }
 }
 
-template <int DT>
-__global__ void scale_add_kernel(const float4* z, const float* gate, const float4* x, void* out, long long HWCq, int Cq,
+template <int XD>
+__device__ __forceinline__ float4 ld_x4(const void* base, long long quad) {
+  if (XD == FCVSR_F32) return reinterpret_cast<const float4*>(base)[quad];
+  const uint2 v = reinterpret_cast<const uint2*>(base)[quad];
+  if (XD == FCVSR_BF16)
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  const h2 a = __builtin_bit_cast(h2, v.x), b = __builtin_bit_cast(h2, v.y);
+  return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+}
+
+template <int DT, int XD>
+__global__ void scale_add_kernel(const float4* z, const float* gate, const void* x, void* out, long long HWCq, int Cq,
                                  long long total) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   const int b = (int)(t / HWCq);
   const int cq = (int)(t % Cq);
   const float* g = gate + (long long)b * Cq * 4 + cq * 4;
-  const float4 zz = z[t], xx = x[t];
+  const float4 zz = z[t], xx = ld_x4<XD>(x, t);
   const float4 o = make_float4(fmaf(zz.x, g[0], xx.x), fmaf(zz.y, g[1], xx.y), fmaf(zz.z, g[2], xx.z), fmaf(zz.w, g[3], xx.w));
   if (DT == FCVSR_F32) {
     reinterpret_cast<float4*>(out)[t] = o;
@@ -108,8 +120,8 @@ extern "C" int fcvsr_divenh(int mode, int first, const float* f, float* s_f, flo
   return 0;
 }
 
-extern "C" int fcvsr_scale_add(const float* z, const float* gate, const float* x, void* out, int out_dtype, int B, int H,
-                               int W, int C, void* stream) {
+extern "C" int fcvsr_scale_add(const float* z, const float* gate, const void* x, int x_dtype, void* out, int out_dtype, int B,
+                               int H, int W, int C, void* stream) {
   FCVSR_CHECK_ARG(z && gate && x && out, "null pointer");
   FCVSR_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "C%4==0 required");
   FCVSR_CHECK_ARG(((uintptr_t)z % 16 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0), "16-byte alignment");
@@ -117,15 +129,14 @@ extern "C" int fcvsr_scale_add(const float* z, const float* gate, const float* x
   const long long HWCq = (long long)H * W * Cq;
   const long long total = HWCq * B;
   FCVSR_CHECK_ARG(out_dtype == FCVSR_F32 || out_dtype == FCVSR_BF16 || out_dtype == FCVSR_F16, "bad out_dtype");
-  if (out_dtype == FCVSR_F32)
-    hipLaunchKernelGGL((scale_add_kernel<FCVSR_F32>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)z,
-                       gate, (const float4*)x, out, HWCq, Cq, total);
-  else if (out_dtype == FCVSR_BF16)
-    hipLaunchKernelGGL((scale_add_kernel<FCVSR_BF16>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)z,
-                       gate, (const float4*)x, out, HWCq, Cq, total);
-  else
-    hipLaunchKernelGGL((scale_add_kernel<FCVSR_F16>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)z,
-                       gate, (const float4*)x, out, HWCq, Cq, total);
+  FCVSR_CHECK_ARG(x_dtype == FCVSR_F32 || x_dtype == out_dtype, "x must be f32 or stored like out");
+  dim3 grid(cdiv(total, 256));
+  hipStream_t st = (hipStream_t)stream;
+#define FCVSR_SA(OD, XD) hipLaunchKernelGGL((scale_add_kernel<OD, XD>), grid, dim3(256), 0, st, (const float4*)z, gate, x, out, HWCq, Cq, total)
+  if (out_dtype == FCVSR_F32) FCVSR_SA(FCVSR_F32, FCVSR_F32);
+  else if (out_dtype == FCVSR_BF16) { if (x_dtype == FCVSR_F32) FCVSR_SA(FCVSR_BF16, FCVSR_F32); else FCVSR_SA(FCVSR_BF16, FCVSR_BF16); }
+  else { if (x_dtype == FCVSR_F32) FCVSR_SA(FCVSR_F16, FCVSR_F32); else FCVSR_SA(FCVSR_F16, FCVSR_F16); }
+#undef FCVSR_SA
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

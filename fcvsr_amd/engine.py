@@ -178,7 +178,7 @@ class Engine:
 
     def _tap(self, name, t_nhwc):
         if self.taps is not None:
-            self.taps[name] = t_nhwc.permute(0, 3, 1, 2).contiguous().clone()
+            self.taps[name] = t_nhwc.float().permute(0, 3, 1, 2).contiguous().clone()
 
     @staticmethod
     def _new(dev, *shape, dtype=torch.float32):
@@ -274,9 +274,12 @@ class Engine:
         self._conv("MGAA.F.1", [k0], K)
 
         # iterative alignment: warp -> SAC(kernel1 twice) -> + feat_in -> LeakyReLU(0.1)
-        al = self._new(dev, B, H, W, 2 * n)
-        ping = [self._new(dev, B, H, W, n), self._new(dev, B, H, W, n)]
+        fdt_act = x1.dtype                               # f32, or the 16-bit activation dtype (trunk16)
+        al = self._new(dev, B, H, W, 2 * n, dtype=fdt_act)
+        ping = [self._new(dev, B, H, W, n, dtype=fdt_act), self._new(dev, B, H, W, n, dtype=fdt_act)]
         if not fused_iac:
+            if fdt_act != torch.float32:
+                raise RuntimeError("16-bit activations need the fused IAC kernel (n_features % 32 == 0)")
             s = self._new(dev, B, H, W, n)
             vbuf = self._new(dev, B, H, W, n)
         for d, fin in enumerate((x1, x3)):
@@ -298,7 +301,7 @@ class Engine:
                     check(L.fcvsr_sac_h(C.byref(v_v), C.byref(k_v), C.byref(fv), 0.1, B, H, W, C.byref(d_v), st),
                           "fcvsr_sac_h")
                 cur = dst
-        out = self._new(dev, B, H, W, n)
+        out = self._new(dev, B, H, W, n, dtype=fdt_act)
         self._conv("MGAA.conv3", [al], out, res=[x2])
         if self.taps is not None:
             self._tap(f"mgaa{tag}.off_f", off4[:B])
@@ -355,10 +358,10 @@ class Engine:
                                  B, H, W, n, st), "fcvsr_divenh(apply)")
         g = self._ca_gate(self._channel_sum(s_o), inv_hw, "MFFRblock.ca", B, n)
         out = self._new(dev, B, H, W, n, dtype=out_dtype)
-        check(L.fcvsr_scale_add(s_o.data_ptr(), g.data_ptr(), x.data_ptr(), out.data_ptr(), self._code(out_dtype), B, H, W,
-                                n, st), "fcvsr_scale_add")
+        check(L.fcvsr_scale_add(s_o.data_ptr(), g.data_ptr(), x.data_ptr(), self._code(x.dtype), out.data_ptr(),
+                                self._code(out_dtype), B, H, W, n, st), "fcvsr_scale_add")
         if self.taps is not None:
-            self.taps["mffr.bands"] = torch.stack([f.permute(0, 3, 1, 2) for f in freq], 1).contiguous().clone()
+            self.taps["mffr.bands"] = torch.stack([f.float().permute(0, 3, 1, 2) for f in freq], 1).contiguous().clone()
             self._tap("mffr.out", out.float())
         return out
 
@@ -515,7 +518,9 @@ class Engine:
         st = stream_ptr()
         a_t = m.lrelu.weight
         xin = x.view(B, T * Cimg, H, W).permute(0, 2, 3, 1)      # (b,y,x,c) strided view of the NCHW frames
-        feat = self._new(dev, B, H, W, 7 * n)
+        # 16-bit activation storage with trunk16.  feat_extract always multiplies in f16 (8-bit pixels stay exact), so its
+        # output can only be stored as f16: in bf16 mode the features / MGAA tensors stay f32 and trunk16 covers SCNetbk only.
+        feat = self._new(dev, B, H, W, 7 * n, dtype=self._tdt() if self.precision == "f16" else torch.float32)
         self._conv("feat_extract.0", [xin], feat, force_f16=True)
         self._tap("feat", feat)
         f1, f2, f3 = feat[..., :3 * n], feat[..., 3 * n:4 * n], feat[..., 4 * n:]

@@ -92,7 +92,7 @@ int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int mma_dtype,
 /* ---- frequency transforms: torch.fft.rfft2 / irfft2 (norm='backward') of NHWC channel groups -------------
  * Spectrum layout: buffer [B][H][Wf][pix_stride] with Wf=W/2+1; channel c of the group has its imaginary part at
  * channel im_off+c and its real part at re_off+c (the reference packs [imag, real], CVSR_freq.py:1456-1465).
- * fcvsr_rfft2 : real src (B,H,W,n) -> spectrum            (replaces :1452-1465 and the fftn of :2082-2084)
+ * fcvsr_rfft2 : real src (B,H,W,n; f32 or 16-bit storage) -> f32 spectrum  (replaces :1452-1465 and the fftn of :2082-2084)
  * fcvsr_irfft2: spectrum (optionally multiplied by a real (H,Wf) mask per group of `mask_every` channels...)
  *               -> real dst (B,H,W,n), scaled 1/(H*W)     (replaces :1497-1505 and the ifftn(...).real of :2085-2090)
  *   work: scratch buffer of the same size as the spectrum region used (B*H*Wf*2n floats), or NULL to run the
@@ -128,7 +128,8 @@ int fcvsr_sac_h(const fcvsr_view* v, const fcvsr_view* k1, const fcvsr_view* fea
                 int B, int H, int W, const fcvsr_view* dst, void* stream);
 
 /* One fused IAC iteration (:1230-1250): dst = LeakyReLU_slope(SAC_h(SAC_v(flow_warp(prev, off), k1), k1) + feat_in).
- * k1: the 3*C kernel1 channels of this iteration, f32 or 16-bit (FCVSR_BF16/FCVSR_F16); everything else f32. C % 32 == 0. */
+ * k1: the 3*C kernel1 channels of this iteration, f32 or 16-bit; prev / feat_in / dst: f32 or 16-bit (all alike);
+ * off f32.  C % 32 == 0. */
 int fcvsr_iac_step(const fcvsr_view* prev, const fcvsr_view* off, const fcvsr_view* k1, const fcvsr_view* feat_in,
                    float slope, int B, int H, int W, const fcvsr_view* dst, void* stream);
 
@@ -139,9 +140,9 @@ int fcvsr_iac_step(const fcvsr_view* prev, const fcvsr_view* off, const fcvsr_vi
 int fcvsr_divenh(int mode, int first, const float* f, float* s_f, float* s_o, const float* a, const float* b,
                  const float* mean_f_sum, float inv_hw, const float* g1, const float* g2,
                  float* sums, float* scratch, int64_t scratch_elems, int B, int H, int W, int C, void* stream);
-/* out = z*gate[b][c] + x   (final CALayer of MFFR, :2229-2230); out stored as out_dtype */
-int fcvsr_scale_add(const float* z, const float* gate, const float* x, void* out, int out_dtype, int B, int H, int W, int C,
-                    void* stream);
+/* out = z*gate[b][c] + x   (final CALayer of MFFR, :2229-2230); x read as x_dtype, out stored as out_dtype */
+int fcvsr_scale_add(const float* z, const float* gate, const void* x, int x_dtype, void* out, int out_dtype, int B, int H,
+                    int W, int C, void* stream);
 
 /* ---- SCNetbk pieces (CVSR_freq.py:657-822) ------------------------------------------------------------------- */
 /* ContextBlock (:657-701): add[b][c] = W2 lrelu0.2(W1 ctx), ctx = sum_p r[p]*softmax_p(r[p].wmask)

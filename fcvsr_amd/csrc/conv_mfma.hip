@@ -56,6 +56,7 @@ struct MfmaArgs {
   int ps;
   int flat;            // 1x1: treat pixels as a flat list of B*H*W
   int src16, dst16;    // sources / destination stored in the MFMA dtype (16-bit) instead of f32
+  int dstbf;           // the 16-bit destination format is bf16 (generic kernel: may differ from the MFMA dtype)
   int res16;           // residual inputs stored in the MFMA dtype (lean 3x3 kernel only: 16-bit trunk)
   const float* gc_wmask;   // ContextBlock fusion: per-wave online-softmax partials of the output (cout <= 64, 3x3)
   int planar;          // single f32 source with arbitrary channel stride (the NCHW frames of feat_extract), cin <= 64
@@ -83,7 +84,7 @@ __device__ __forceinline__ f32x16_t mfma(uint4 a, uint4 b, f32x16_t c) {
 }
 
 struct EpiCtx {
-  int act, n_res, ps, flat, H, W, b, dst16, sub2, cq4;   // cq4 = cout/4 (pixel-shuffle: couts are ordered sub-pixel-major)
+  int act, n_res, ps, flat, H, W, b, dst16, dstbf, sub2, cq4;   // dstbf: 16-bit destination is bf16 (may differ from the MFMA dtype)   // cq4 = cout/4 (pixel-shuffle: couts are ordered sub-pixel-major)
   float slope, rs0, rs1;
   long long npix;
   View res0, res1, dst;
@@ -159,7 +160,7 @@ __device__ __forceinline__ bool epilogue_quad(const EpiCtx& e, float4 v, const f
   }
   if (e.dst16) {
     uint16_t* dp = reinterpret_cast<uint16_t*>(d.p);
-    const uint2 pk = cvt4<BF16>(make_float4(x[0], x[1], x[2], x[3]));
+    const uint2 pk = e.dstbf ? cvt4<true>(make_float4(x[0], x[1], x[2], x[3])) : cvt4<false>(make_float4(x[0], x[1], x[2], x[3]));
     if (full && d.sc == 1) {
       *reinterpret_cast<uint2*>(dp + o + nn) = pk;
     } else {
@@ -217,7 +218,9 @@ __device__ __forceinline__ void epilogue_oct(const EpiCtx& e, float4 va, float4 
   }
   const View& d = e.dst;
   const int o = (e.flat ? (int)pflat * (int)d.sx : (e.b * (int)d.sb + py * (int)d.sy + px * (int)d.sx));
-  const uint2 lo = cvt4<BF16>(make_float4(x[0], x[1], x[2], x[3])), hi = cvt4<BF16>(make_float4(x[4], x[5], x[6], x[7]));
+  uint2 lo, hi;
+  if (e.dstbf) { lo = cvt4<true>(make_float4(x[0], x[1], x[2], x[3])); hi = cvt4<true>(make_float4(x[4], x[5], x[6], x[7])); }
+  else { lo = cvt4<false>(make_float4(x[0], x[1], x[2], x[3])); hi = cvt4<false>(make_float4(x[4], x[5], x[6], x[7])); }
   *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.p) + o + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(256, MW == 1 ? (WD ? (NT == 128 ? 2 : 3) : (NT == 1
   EpiCtx e;
   e.act = a.act; e.slope = slope; e.n_res = a.n_res; e.rs0 = a.rs[0]; e.rs1 = a.rs[1]; e.ps = a.ps; e.flat = a.flat;
   e.res0 = G.res[0]; e.res1 = G.res[1]; e.dst = G.dst; e.H = G.H; e.W = G.W; e.b = b; e.npix = npix;
-  e.dst16 = a.dst16; e.cq4 = a.cout >> 2; e.sub2 = a.sub2;
+  e.dst16 = a.dst16; e.dstbf = a.dstbf; e.cq4 = a.cout >> 2; e.sub2 = a.sub2;
   constexpr int EW = NT >= 64 ? 64 : 32;        // couts per pass
   constexpr int EROW = EW + 4;                  // padded row (floats): conflict-free b32 writes and b128 reads
   constexpr int QPR = EW / 4;                   // float4 per pixel row
@@ -1256,6 +1259,8 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   FCVSR_CHECK_ARG(!a.planar || (d0.src[0].dtype == FCVSR_F32 && d0.src[0].c <= 32 && d0.kh == 3),
                   "planar (channel-strided) source: one f32 source with <= 32 channels, 3x3");
   a.dst16 = d0.dst.dtype != FCVSR_F32;
+  a.dstbf = d0.dst.dtype == FCVSR_BF16;
+  const bool dst_native = d0.dst.dtype == FCVSR_F32 || d0.dst.dtype == mma_dtype;   // lean kernels store f32 / MFMA dtype only
   a.n_groups = n_groups;
   a.n_src = d0.n_src;
   a.n_res = d0.n_res;
@@ -1332,8 +1337,8 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
       if (a.flat)
         FCVSR_CHECK_ARG(d.res[q].sy == d.res[q].sx * d.W && d.res[q].sb == d.res[q].sy * d.H, "1x1 needs uniformly strided res");
     }
-    FCVSR_CHECK_ARG(d.dst.ptr && (d.dst.dtype == FCVSR_F32 || d.dst.dtype == mma_dtype) && d.dst.dtype == d0.dst.dtype &&
-                        vec_view_ok(d.dst), "dst must be f32 or the MFMA dtype, vector-aligned");
+    FCVSR_CHECK_ARG(d.dst.ptr && (d.dst.dtype == FCVSR_F32 || d.dst.dtype == FCVSR_BF16 || d.dst.dtype == FCVSR_F16) &&
+                        d.dst.dtype == d0.dst.dtype && vec_view_ok(d.dst), "dst must be f32 / bf16 / f16, vector-aligned");
     FCVSR_CHECK_ARG(d.bias == nullptr || ((uintptr_t)d.bias % 16) == 0, "bias must be 16-byte aligned");
     G.dst = to_view(d.dst);
     if (a.flat && !d.pixel_shuffle)
@@ -1354,7 +1359,7 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   for (int g = n_groups; g < 3; ++g) a.g[g] = a.g[0];
   hipStream_t st = (hipStream_t)stream;
   // lean fast path: 3x3 stride 1, one dense source, cin multiple of 64, plain channel-contiguous destination and residuals
-  bool lean = d0.kh == 3 && d0.stride == 1 && mw == 1 && !wd && d0.n_src == 1 && !a.planar && !a.ps && (cin % 64 == 0) &&
+  bool lean = dst_native && d0.kh == 3 && d0.stride == 1 && mw == 1 && !wd && d0.n_src == 1 && !a.planar && !a.ps && (cin % 64 == 0) &&
               (!a.dst16 || d0.cout % 8 == 0) && (d0.gc_wmask == nullptr || d0.cout % 4 == 0);
   for (int g = 0; g < n_groups && lean; ++g) {
     const fcvsr_conv_desc& d = descs[g];
@@ -1371,7 +1376,7 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   }
   // lean 1x1 (flat) path: every source a multiple of 64 channels, channel-contiguous destination, f32 residuals;
   // pixel shuffle only without residuals
-  bool lean1 = d0.kh == 1 && mw == 1 && !wd && nt <= 64 && (d0.cout % 8 == 0) && !a.planar;
+  bool lean1 = dst_native && d0.kh == 1 && mw == 1 && !wd && nt <= 64 && (d0.cout % 8 == 0) && !a.planar;
   for (int s2 = 0; s2 < d0.n_src && lean1; ++s2) lean1 = lean1 && (d0.src[s2].c % 64 == 0);
   lean1 = lean1 && (!a.ps || (d0.n_res == 0 && (d0.cout / 4) % 8 == 0));
   for (int g = 0; g < n_groups && lean1; ++g) {

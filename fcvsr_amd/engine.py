@@ -518,9 +518,9 @@ class Engine:
         st = stream_ptr()
         a_t = m.lrelu.weight
         xin = x.view(B, T * Cimg, H, W).permute(0, 2, 3, 1)      # (b,y,x,c) strided view of the NCHW frames
-        # 16-bit activation storage with trunk16.  feat_extract always multiplies in f16 (8-bit pixels stay exact), so its
-        # output can only be stored as f16: in bf16 mode the features / MGAA tensors stay f32 and trunk16 covers SCNetbk only.
-        feat = self._new(dev, B, H, W, 7 * n, dtype=self._tdt() if self.precision == "f16" else torch.float32)
+        # 16-bit activation storage with trunk16 (feat_extract multiplies in f16 - 8-bit pixels stay exact - and stores its
+        # output in the mode's activation dtype)
+        feat = self._new(dev, B, H, W, 7 * n, dtype=self._tdt())
         self._conv("feat_extract.0", [xin], feat, force_f16=True)
         self._tap("feat", feat)
         f1, f2, f3 = feat[..., :3 * n], feat[..., 3 * n:4 * n], feat[..., 4 * n:]

@@ -147,15 +147,16 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
                 pm = json.load(f)
             c = pm["config"]
-            if (c["model"], c["batch"], c["precision"], c["height"], c["width"]) == (args.model, B, args.precision, H, W) \
-                    and kind == "mfma":
+            if (c["model"], c["batch"], c["precision"], c["height"], c["width"], c.get("act16", False)) == \
+                    (args.model, B, args.precision, H, W, bool(args.trunk16)) and kind == "mfma":
                 traffic = round(pm["hbm_bytes_per_launch"])
         except Exception:
             traffic = None
         alg_bytes = sum(r[5] for r in dom) / max(1, len(dom))
         roofline = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 5), "traffic": traffic, "algorithmic_bytes_per_launch": round(alg_bytes),
-                    "kernel": "conv_direct_kernel" if kind == "direct" else "conv_mfma_kernel",
+                    "kernel": "conv_direct_kernel" if kind == "direct"
+                    else "MFMA conv class (conv3_lean_kernel, conv1_lean_kernel, conv_mfma_kernel)",
                     "launches_per_step": len(dom), "avg_launch_us": round(tot_ms * 1e3 / max(1, len(dom)), 2),
                     "flops_per_step_kernel": tot_fl, "flops_per_step_all_convs": all_fl,
                     "kernel_ms_per_step": round(tot_ms, 3)}

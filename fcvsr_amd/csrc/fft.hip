@@ -187,8 +187,20 @@ __device__ __forceinline__ float ld_act(const float* base, long long idx, int dt
   return (float)__builtin_bit_cast(_Float16, u);
 }
 
+__device__ __forceinline__ float4 ld_act4(const float* base, long long idx, int dt) {
+  if (dt == FCVSR_F32) return *reinterpret_cast<const float4*>(base + idx);
+  const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+  if (dt == FCVSR_BF16)
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  const h2 a = __builtin_bit_cast(h2, v.x), b = __builtin_bit_cast(h2, v.y);
+  return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+}
+
+// `vec`: every channel of the workgroup's chunk exists and all offsets are 4-channel aligned -> 16-byte accesses
 __global__ __launch_bounds__(512) void rfft_rows_kernel(View src, int src_dt, int n, int H, int W, int L, float* spec,
-                                                        long long ps, int im_off, int re_off, FftPlan plan) {
+                                                        long long ps, int im_off, int re_off, FftPlan plan, int vec) {
   extern __shared__ __align__(16) float lds[];
   const int NL = W * L;
   const int b = blockIdx.y / H, y = blockIdx.y % H;
@@ -196,18 +208,46 @@ __global__ __launch_bounds__(512) void rfft_rows_kernel(View src, int src_dt, in
   const int Wf = W / 2 + 1;
   make_twiddles(lds + 4 * NL, W, false);
   const long long sp = (long long)b * src.sb + (long long)y * src.sy;
-  for (int t = threadIdx.x; t < NL; t += blockDim.x) {
-    const int l = t & (L - 1), x = t >> (31 - __clz(L));
-    const int ca = c0 + l, cb = c0 + L + l;
-    const long long px = sp + (long long)x * src.sx;
-    lds[t] = ca < n ? ld_act(src.p, px + (long long)ca * src.sc, src_dt) : 0.f;
-    lds[NL + t] = cb < n ? ld_act(src.p, px + (long long)cb * src.sc, src_dt) : 0.f;
+  const int logL = 31 - __clz(L);
+  if (vec) {
+    const int G4 = L >> 1;                         // 4-channel groups per pixel (2L channels)
+    const int logG = logL - 1;
+    for (int t = threadIdx.x; t < W * G4; t += blockDim.x) {
+      const int g = t & (G4 - 1), x = t >> logG;
+      const int j0 = g * 4;                        // channel offset inside the chunk: [0,L) -> real lane, [L,2L) -> imag lane
+      const float4 v = ld_act4(src.p, sp + (long long)x * src.sx + c0 + j0, src_dt);
+      float* d = (j0 < L) ? (lds + x * L + j0) : (lds + NL + x * L + (j0 - L));
+      *reinterpret_cast<float4*>(d) = v;
+    }
+  } else {
+    for (int t = threadIdx.x; t < NL; t += blockDim.x) {
+      const int l = t & (L - 1), x = t >> logL;
+      const int ca = c0 + l, cb = c0 + L + l;
+      const long long px = sp + (long long)x * src.sx;
+      lds[t] = ca < n ? ld_act(src.p, px + (long long)ca * src.sc, src_dt) : 0.f;
+      lds[NL + t] = cb < n ? ld_act(src.p, px + (long long)cb * src.sc, src_dt) : 0.f;
+    }
   }
   __syncthreads();
   const int cur = run_stages<false>(lds, plan, L);
   const float* zr = lds + (cur ? 2 * NL : 0);
   const float* zi = zr + NL;
   float* op = spec + ((long long)(b * H + y) * Wf) * ps;
+  if (vec) {
+    const int Q4 = L >> 2, logQ = logL - 2;
+    for (int t = threadIdx.x; t < Wf * Q4; t += blockDim.x) {
+      const int q = t & (Q4 - 1), k = t >> logQ;
+      const int kn = (W - k) % W;
+      const float4 kr = *reinterpret_cast<const float4*>(zr + k * L + q * 4), ki = *reinterpret_cast<const float4*>(zi + k * L + q * 4);
+      const float4 nr = *reinterpret_cast<const float4*>(zr + kn * L + q * 4), ni = *reinterpret_cast<const float4*>(zi + kn * L + q * 4);
+      float* o = op + (long long)k * ps + c0 + q * 4;
+      *reinterpret_cast<float4*>(o + re_off) = make_float4(0.5f * (kr.x + nr.x), 0.5f * (kr.y + nr.y), 0.5f * (kr.z + nr.z), 0.5f * (kr.w + nr.w));
+      *reinterpret_cast<float4*>(o + im_off) = make_float4(0.5f * (ki.x - ni.x), 0.5f * (ki.y - ni.y), 0.5f * (ki.z - ni.z), 0.5f * (ki.w - ni.w));
+      *reinterpret_cast<float4*>(o + re_off + L) = make_float4(0.5f * (ki.x + ni.x), 0.5f * (ki.y + ni.y), 0.5f * (ki.z + ni.z), 0.5f * (ki.w + ni.w));
+      *reinterpret_cast<float4*>(o + im_off + L) = make_float4(0.5f * (nr.x - kr.x), 0.5f * (nr.y - kr.y), 0.5f * (nr.z - kr.z), 0.5f * (nr.w - kr.w));
+    }
+    return;
+  }
   for (int t = threadIdx.x; t < Wf * L; t += blockDim.x) {
     const int l = t & (L - 1), k = t >> (31 - __clz(L));
     const int kn = (W - k) % W;
@@ -223,24 +263,47 @@ __global__ __launch_bounds__(512) void rfft_rows_kernel(View src, int src_dt, in
 // ---- columns: complex length-H transform of spectrum columns, forward or inverse, optional real mask -----------
 __global__ __launch_bounds__(512) void fft_cols_kernel(const float* in, float* out, long long ps, int im_off, int re_off,
                                                        int n, int H, int Wf, int L, int inverse, const float* mask,
-                                                       FftPlan plan) {
+                                                       FftPlan plan, int vec) {
   extern __shared__ __align__(16) float lds[];
   const int NL = H * L;
   const int b = blockIdx.y / Wf, kx = blockIdx.y % Wf;
   const int c0 = blockIdx.x * L;
   make_twiddles(lds + 4 * NL, H, inverse != 0);
-  for (int t = threadIdx.x; t < NL; t += blockDim.x) {
-    const int l = t & (L - 1), y = t >> (31 - __clz(L));
-    const int c = c0 + l;
-    const float* px = in + ((long long)(b * H + y) * Wf + kx) * ps;
-    const float m = mask ? mask[y * Wf + kx] : 1.f;
-    lds[t] = c < n ? px[re_off + c] * m : 0.f;
-    lds[NL + t] = c < n ? px[im_off + c] * m : 0.f;
+  const int logL = 31 - __clz(L);
+  if (vec) {
+    const int Q4 = L >> 2, logQ = logL - 2;
+    for (int t = threadIdx.x; t < H * Q4; t += blockDim.x) {
+      const int q = t & (Q4 - 1), y = t >> logQ;
+      const float* px = in + ((long long)(b * H + y) * Wf + kx) * ps + c0 + q * 4;
+      const float m = mask ? mask[y * Wf + kx] : 1.f;
+      const float4 vr = *reinterpret_cast<const float4*>(px + re_off), vi = *reinterpret_cast<const float4*>(px + im_off);
+      *reinterpret_cast<float4*>(lds + y * L + q * 4) = make_float4(vr.x * m, vr.y * m, vr.z * m, vr.w * m);
+      *reinterpret_cast<float4*>(lds + NL + y * L + q * 4) = make_float4(vi.x * m, vi.y * m, vi.z * m, vi.w * m);
+    }
+  } else {
+    for (int t = threadIdx.x; t < NL; t += blockDim.x) {
+      const int l = t & (L - 1), y = t >> logL;
+      const int c = c0 + l;
+      const float* px = in + ((long long)(b * H + y) * Wf + kx) * ps;
+      const float m = mask ? mask[y * Wf + kx] : 1.f;
+      lds[t] = c < n ? px[re_off + c] * m : 0.f;
+      lds[NL + t] = c < n ? px[im_off + c] * m : 0.f;
+    }
   }
   __syncthreads();
   const int cur = inverse ? run_stages<true>(lds, plan, L) : run_stages<false>(lds, plan, L);
   const float* zr = lds + (cur ? 2 * NL : 0);
   const float* zi = zr + NL;
+  if (vec) {
+    const int Q4 = L >> 2, logQ = logL - 2;
+    for (int t = threadIdx.x; t < H * Q4; t += blockDim.x) {
+      const int q = t & (Q4 - 1), y = t >> logQ;
+      float* px = out + ((long long)(b * H + y) * Wf + kx) * ps + c0 + q * 4;
+      *reinterpret_cast<float4*>(px + re_off) = *reinterpret_cast<const float4*>(zr + y * L + q * 4);
+      *reinterpret_cast<float4*>(px + im_off) = *reinterpret_cast<const float4*>(zi + y * L + q * 4);
+    }
+    return;
+  }
   for (int t = threadIdx.x; t < NL; t += blockDim.x) {
     const int l = t & (L - 1), y = t >> (31 - __clz(L));
     const int c = c0 + l;
@@ -254,7 +317,7 @@ __global__ __launch_bounds__(512) void fft_cols_kernel(const float* in, float* o
 
 // ---- inverse rows: half spectrum -> real (c2r semantics: imag of DC / Nyquist ignored), two channels per lane ----
 __global__ __launch_bounds__(512) void irfft_rows_kernel(const float* spec, long long ps, int im_off, int re_off, int n,
-                                                         int H, int W, int L, View dst, float scale, FftPlan plan) {
+                                                         int H, int W, int L, View dst, float scale, FftPlan plan, int vec) {
   extern __shared__ __align__(16) float lds[];
   const int NL = W * L;
   const int b = blockIdx.y / H, y = blockIdx.y % H;
@@ -262,8 +325,25 @@ __global__ __launch_bounds__(512) void irfft_rows_kernel(const float* spec, long
   const int Wf = W / 2 + 1;
   make_twiddles(lds + 4 * NL, W, true);
   const float* ip = spec + ((long long)(b * H + y) * Wf) * ps;
+  const int logL = 31 - __clz(L);
+  if (vec) {
+    const int Q4 = L >> 2, logQ = logL - 2;
+    for (int t = threadIdx.x; t < W * Q4; t += blockDim.x) {
+      const int q = t & (Q4 - 1), k = t >> logQ;
+      const int kk = (k <= W / 2) ? k : W - k;
+      const float sgn = (k > W / 2) ? -1.f : 1.f;
+      const float keep = ((kk == 0) || ((W % 2 == 0) && kk == W / 2)) ? 0.f : sgn;   // imag parts: dropped at DC/Nyquist
+      const float* px = ip + (long long)kk * ps + c0 + q * 4;
+      const float4 ar = *reinterpret_cast<const float4*>(px + re_off), ai = *reinterpret_cast<const float4*>(px + im_off);
+      const float4 br = *reinterpret_cast<const float4*>(px + re_off + L), bi = *reinterpret_cast<const float4*>(px + im_off + L);
+      *reinterpret_cast<float4*>(lds + k * L + q * 4) =
+          make_float4(ar.x - keep * bi.x, ar.y - keep * bi.y, ar.z - keep * bi.z, ar.w - keep * bi.w);
+      *reinterpret_cast<float4*>(lds + NL + k * L + q * 4) =
+          make_float4(keep * ai.x + br.x, keep * ai.y + br.y, keep * ai.z + br.z, keep * ai.w + br.w);
+    }
+  } else
   for (int t = threadIdx.x; t < NL; t += blockDim.x) {
-    const int l = t & (L - 1), k = t >> (31 - __clz(L));
+    const int l = t & (L - 1), k = t >> logL;
     const int kk = (k <= W / 2) ? k : W - k;
     const bool cj = k > W / 2;
     const bool real_only = (kk == 0) || ((W % 2 == 0) && kk == W / 2);
@@ -282,8 +362,19 @@ __global__ __launch_bounds__(512) void irfft_rows_kernel(const float* spec, long
   const float* zr = lds + (cur ? 2 * NL : 0);
   const float* zi = zr + NL;
   float* op = dst.p + (long long)b * dst.sb + (long long)y * dst.sy;
+  if (vec) {
+    const int Q4 = L >> 2, logQ = logL - 2;
+    for (int t = threadIdx.x; t < W * Q4; t += blockDim.x) {
+      const int q = t & (Q4 - 1), x = t >> logQ;
+      float* px = op + (long long)x * dst.sx + c0 + q * 4;
+      const float4 a4 = *reinterpret_cast<const float4*>(zr + x * L + q * 4), b4 = *reinterpret_cast<const float4*>(zi + x * L + q * 4);
+      *reinterpret_cast<float4*>(px) = make_float4(a4.x * scale, a4.y * scale, a4.z * scale, a4.w * scale);
+      *reinterpret_cast<float4*>(px + L) = make_float4(b4.x * scale, b4.y * scale, b4.z * scale, b4.w * scale);
+    }
+    return;
+  }
   for (int t = threadIdx.x; t < NL; t += blockDim.x) {
-    const int l = t & (L - 1), x = t >> (31 - __clz(L));
+    const int l = t & (L - 1), x = t >> logL;
     const int ca = c0 + l, cb = c0 + L + l;
     float* px = op + (long long)x * dst.sx;
     if (ca < n) px[(long long)ca * dst.sc] = zr[t] * scale;
@@ -326,14 +417,18 @@ extern "C" int fcvsr_rfft2(const fcvsr_view* src, int B, int H, int W, int n, fl
   FCVSR_CHECK_ARG(make_plan(W, &pw) && make_plan(H, &ph), "length has too many factors");
   const int Wf = W / 2 + 1;
   hipStream_t st = (hipStream_t)stream;
+  const bool spec_ok = pix_stride % 4 == 0 && im_off % 4 == 0 && re_off % 4 == 0 && ((uintptr_t)spec % 16) == 0;
   {
     const int L = pick_lanes(W, (n + 1) / 2);
     FCVSR_CHECK_ARG(16ll * W * L + 8ll * W <= 160 * 1024, "row too long for LDS");
     const size_t lds = 16ull * W * L + 8ull * W;
     (void)allow_lds(rfft_rows_kernel, lds);
     dim3 grid(cdiv(n, 2 * L), B * H);
+    const int sal = src->dtype == FCVSR_F32 ? 16 : 8;
+    const int vec = (L >= 4 && n % (2 * L) == 0 && src->sc == 1 && src->sx % 4 == 0 && src->sy % 4 == 0 && src->sb % 4 == 0 &&
+                     ((uintptr_t)src->ptr % sal) == 0 && spec_ok) ? 1 : 0;
     hipLaunchKernelGGL(rfft_rows_kernel, grid, dim3(512), lds, st, to_view(*src), (int)src->dtype, n, H, W, L, spec,
-                       (long long)pix_stride, im_off, re_off, pw);
+                       (long long)pix_stride, im_off, re_off, pw, vec);
     FCVSR_LAUNCH_CHECK();
   }
   {
@@ -342,8 +437,9 @@ extern "C" int fcvsr_rfft2(const fcvsr_view* src, int B, int H, int W, int n, fl
     const size_t lds = 16ull * H * L + 8ull * H;
     (void)allow_lds(fft_cols_kernel, lds);
     dim3 grid(cdiv(n, L), B * Wf);
+    const int vec = (L >= 4 && n % L == 0 && spec_ok) ? 1 : 0;
     hipLaunchKernelGGL(fft_cols_kernel, grid, dim3(512), lds, st, (const float*)spec, spec, (long long)pix_stride, im_off,
-                       re_off, n, H, Wf, L, 0, (const float*)nullptr, ph);
+                       re_off, n, H, Wf, L, 0, (const float*)nullptr, ph, vec);
     FCVSR_LAUNCH_CHECK();
   }
   return 0;
@@ -359,14 +455,16 @@ extern "C" int fcvsr_irfft2(const float* spec, int64_t pix_stride, int im_off, i
   const int Wf = W / 2 + 1;
   hipStream_t st = (hipStream_t)stream;
   float* mid = work ? work : const_cast<float*>(spec);
+  const bool spec_ok = pix_stride % 4 == 0 && im_off % 4 == 0 && re_off % 4 == 0 && ((uintptr_t)spec % 16) == 0;
   {
     const int L = pick_lanes(H, n);
     FCVSR_CHECK_ARG(16ll * H * L + 8ll * H <= 160 * 1024, "column too long for LDS");
     const size_t lds = 16ull * H * L + 8ull * H;
     (void)allow_lds(fft_cols_kernel, lds);
     dim3 grid(cdiv(n, L), B * Wf);
+    const int vec = (L >= 4 && n % L == 0 && spec_ok && ((uintptr_t)mid % 16) == 0) ? 1 : 0;
     hipLaunchKernelGGL(fft_cols_kernel, grid, dim3(512), lds, st, spec, mid, (long long)pix_stride, im_off, re_off, n, H,
-                       Wf, L, 1, mask, ph);
+                       Wf, L, 1, mask, ph, vec);
     FCVSR_LAUNCH_CHECK();
   }
   {
@@ -375,8 +473,10 @@ extern "C" int fcvsr_irfft2(const float* spec, int64_t pix_stride, int im_off, i
     const size_t lds = 16ull * W * L + 8ull * W;
     (void)allow_lds(irfft_rows_kernel, lds);
     dim3 grid(cdiv(n, 2 * L), B * H);
+    const int vec = (L >= 4 && n % (2 * L) == 0 && spec_ok && ((uintptr_t)mid % 16) == 0 && dst->sc == 1 && dst->sx % 4 == 0 &&
+                     dst->sy % 4 == 0 && dst->sb % 4 == 0 && ((uintptr_t)dst->ptr % 16) == 0) ? 1 : 0;
     hipLaunchKernelGGL(irfft_rows_kernel, grid, dim3(512), lds, st, (const float*)mid, (long long)pix_stride, im_off,
-                       re_off, n, H, W, L, to_view(*dst), 1.0f / ((float)H * (float)W), pw);
+                       re_off, n, H, W, L, to_view(*dst), 1.0f / ((float)H * (float)W), pw, vec);
     FCVSR_LAUNCH_CHECK();
   }
   return 0;

@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--streams", type=int, default=4, help="HIP streams the batch is split over")
     ap.add_argument("--trunk16", type=int, default=1, help="1: spatial activations / SCNet trunk stored in the MFMA dtype")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the forward from a captured hipGraph")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--device", type=int, default=None, help="override the HIP device index (rehearsing N ranks on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -74,10 +76,14 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    local = local if args.device is None else args.device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from fcvsr_amd import hip
     from fcvsr_amd.arch import CVSR_freq as A
@@ -115,7 +121,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert bool(torch.isfinite(y).all())

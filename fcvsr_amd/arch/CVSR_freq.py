@@ -201,7 +201,7 @@ class _GShiftBase(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: float (B, 7, C, H, W) in [0,1] on a HIP device -> (B, C, 4H, 4W)."""
         from ..engine import Engine
-        if self._engine is None:
+        if self._engine is None or self._engine._model() is not self:      # (a deepcopy carries the source's engine)
             object.__setattr__(self, "_engine", Engine(self))
         return self._engine.forward(x)
 

@@ -84,6 +84,9 @@ class Engine:
         for k, v in sd.items():
             if v.device != dev:
                 raise RuntimeError(f"parameter {k} is on {v.device}, input on {dev}: call model.to(device) first")
+            if v.dtype != torch.float32:
+                raise RuntimeError(f"parameter {k} is {v.dtype}: keep the parameters in float32 and select the arithmetic "
+                                   "with model.precision = 'bf16' | 'f16' instead of casting the module")
         self._packed = {}
         self._pack_epoch += 1
         self._par = sd

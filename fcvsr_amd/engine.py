@@ -107,12 +107,15 @@ class Engine:
             return wp, None
         return w, (b.detach() if b is not None else None)
 
-    def _weights(self, name, kind, ps=False):
+    def _weights(self, name, kind, ps=False, rows=None):
         """kind: 'direct' (f32 [taps][cin][cout16]) | torch.bfloat16 | torch.float16 (MFMA layout; with ps=True the rows
         are in the sub-pixel-major order the MFMA kernel's pixel-shuffle epilogue expects)."""
-        key = (name, kind, ps)
+        key = (name, kind, ps, rows)
         if key not in self._packed:
             w, b = self._logical_weight(name)
+            if rows is not None:                      # a slice of the output channels (feat_extract is run per frame group)
+                w = w[rows[0]:rows[1]]
+                b = b[rows[0]:rows[1]].contiguous() if b is not None else None
             if kind == "direct":
                 pk = hip.pack_conv_weight(w)
             else:
@@ -149,13 +152,13 @@ class Engine:
 
     # ---------------------------------------------------------------------------------------------- helpers
     def _conv(self, name, srcs, dst, *, stride=1, act=ACT_NONE, slope=0.0, slope_t=None, res=(), res_scale=(),
-              ps=False, freq=False, direct=False, force_f16=False):
+              ps=False, freq=False, direct=False, force_f16=False, rows=None):
         self._convg(name, [dict(srcs=srcs, dst=dst, res=res, ps=ps)], stride=stride, act=act, slope=slope,
-                    slope_t=slope_t, res_scale=res_scale, ps=ps, freq=freq, direct=direct, force_f16=force_f16)
+                    slope_t=slope_t, res_scale=res_scale, ps=ps, freq=freq, direct=direct, force_f16=force_f16, rows=rows)
         return dst
 
     def _convg(self, name, groups, *, stride=1, act=ACT_NONE, slope=0.0, slope_t=None, res_scale=(), ps=False,
-               freq=False, direct=False, force_f16=False, gc_wmask=None):
+               freq=False, direct=False, force_f16=False, gc_wmask=None, rows=None):
         """One conv layer applied to 1..3 tensors that share its weights (pyramid levels): a single grouped MFMA launch in
         the 16-bit modes, per-tensor exact-f32 direct launches otherwise."""
         ksz = self._par[name + ".weight"].shape[-1]
@@ -168,12 +171,12 @@ class Engine:
             dt = torch.bfloat16 if (self.precision == "bf16" or freq) else torch.float16
             if force_f16:      # image-domain input in [0,1]: f16's 11-bit significand keeps 8-bit pixels exact
                 dt = torch.float16
-            w, b, cout, _ = self._weights(name, dt, ps)
+            w, b, cout, _ = self._weights(name, dt, ps, rows)
             hip.conv2d_mfma(groups, w, ksz, cout, hip.BF16 if dt == torch.bfloat16 else hip.F16, stride=stride, bias=b, act=act,
                             slope=slope, slope_t=slope_t, res_scale=res_scale, pixel_shuffle=ps, gc_wmask=gc_wmask,
                             name=name)
             return True
-        w, b, cout, _ = self._weights(name, "direct")
+        w, b, cout, _ = self._weights(name, "direct", False, rows)
         for g in groups:
             hip.conv2d(g["srcs"], w, ksz, cout, g["dst"], bias=b, stride=stride, act=act, slope=slope, slope_t=slope_t,
                        res=g.get("res", ()), res_scale=res_scale, pixel_shuffle=ps, name=name)
@@ -523,13 +526,22 @@ class Engine:
         xin = x.view(B, T * Cimg, H, W).permute(0, 2, 3, 1)      # (b,y,x,c) strided view of the NCHW frames
         # 16-bit activation storage with trunk16 (feat_extract multiplies in f16 - 8-bit pixels stay exact - and stores its
         # output in the mode's activation dtype)
-        feat = self._new(dev, B, H, W, 7 * n, dtype=self._tdt())
-        self._conv("feat_extract.0", [xin], feat, force_f16=True)
-        self._tap("feat", feat)
-        f1, f2, f3 = feat[..., :3 * n], feat[..., 3 * n:4 * n], feat[..., 4 * n:]
-        a1 = self._mgaa(f1[..., :n], f1[..., n:2 * n], f1[..., 2 * n:], "1")
-        a3 = self._mgaa(f3[..., :n], f3[..., n:2 * n], f3[..., 2 * n:], "3")
-        a2 = self._mgaa(a1, f2, a3, "2")
+        # feat_extract is launched per frame group so that the two outer groups land in ONE batch-stacked tensor: the first
+        # two MGAA calls of the reference (same weights, independent inputs f1 and f3, :2623-2624) run as one call on 2B.
+        adt = self._tdt()
+        f13 = self._new(dev, 2 * B, H, W, 3 * n, dtype=adt)      # [f1 of every clip | f3 of every clip]
+        f2 = self._new(dev, B, H, W, n, dtype=adt)
+        self._conv("feat_extract.0", [xin], f13[:B], force_f16=True, rows=(0, 3 * n))
+        self._conv("feat_extract.0", [xin], f13[B:], force_f16=True, rows=(4 * n, 7 * n))
+        self._conv("feat_extract.0", [xin], f2, force_f16=True, rows=(3 * n, 4 * n))
+        if self.taps is not None:
+            self._tap("feat", torch.cat([f13[:B].float(), f2.float(), f13[B:].float()], dim=3))
+        a13 = self._mgaa(f13[..., :n], f13[..., n:2 * n], f13[..., 2 * n:], "13")
+        if self.taps is not None:                                  # split the stacked taps back into calls "1" and "3"
+            for k in [k for k in self.taps if k.startswith("mgaa13.")]:
+                v = self.taps.pop(k)
+                self.taps["mgaa1." + k[7:]], self.taps["mgaa3." + k[7:]] = v[:B].contiguous(), v[B:].contiguous()
+        a2 = self._mgaa(a13[:B], f2, a13[B:], "2")
         tdt = self._tdt()
         d0 = self._mffr(a2, out_dtype=tdt)
         d1 = self._new(dev, B, H // 2, W // 2, n, dtype=tdt)

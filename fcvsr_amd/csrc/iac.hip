@@ -8,6 +8,7 @@
 // quads of a pixel are 8 consecutive lanes, so feature accesses are 128-byte runs and the per-pixel adaptive kernels
 // (12 values per quad, channel index c*3+t) are 192/384-byte runs.  HBM-bound: the dominant traffic is K1
 // (3*C values per pixel per step), read once from HBM (second touch hits L2) in f32 or the 16-bit MFMA dtype.
+#include <stdlib.h>
 #include "common.h"
 
 namespace fcvsr {
@@ -162,6 +163,265 @@ __global__ __launch_bounds__(256) void iac_step_kernel(View prev, View off, View
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 64-channel variant (C % 64 == 0): a lane owns 8 channels of a pixel, so feature accesses are 16-byte (16-bit storage) or
+// 2 x 16-byte (f32) loads in full 128/256-byte runs per pixel and the adaptive kernels are 3 x 16-byte loads in 384-byte runs.
+// Every load that does not depend on the offsets (K1 of the lane's pixels, feat_in) is issued before the warp phase, and
+// phases 2 and 3 use the same lane <-> pixel mapping so K1 is fetched once and kept (packed) in registers.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kJC = 64;
+
+template <int DT>
+struct Pack8 {                                   // 8 channels of a feature tensor as loaded from memory
+  uint4 a, b;                                    // f32: a, b = 8 floats; 16-bit: a only
+};
+
+template <int DT>
+__device__ __forceinline__ Pack8<DT> ld_p8(const float* base, long long elem) {
+  Pack8<DT> r;
+  if (DT == FCVSR_F32) {
+    const uint4* p = reinterpret_cast<const uint4*>(base + elem);
+    r.a = p[0]; r.b = p[1];
+  } else {
+    r.a = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + elem);
+    r.b = make_uint4(0, 0, 0, 0);
+  }
+  return r;
+}
+
+template <int DT>
+__device__ __forceinline__ void cvt2(unsigned w, float& lo, float& hi) {
+  if (DT == FCVSR_BF16) {
+    lo = __uint_as_float(w << 16);
+    hi = __uint_as_float(w & 0xffff0000u);
+  } else {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    const h2 hv = __builtin_bit_cast(h2, w);
+    lo = (float)hv[0];
+    hi = (float)hv[1];
+  }
+}
+
+template <int DT>
+__device__ __forceinline__ void unpack8(const Pack8<DT>& r, float* o) {
+  if (DT == FCVSR_F32) {
+    o[0] = __uint_as_float(r.a.x); o[1] = __uint_as_float(r.a.y); o[2] = __uint_as_float(r.a.z); o[3] = __uint_as_float(r.a.w);
+    o[4] = __uint_as_float(r.b.x); o[5] = __uint_as_float(r.b.y); o[6] = __uint_as_float(r.b.z); o[7] = __uint_as_float(r.b.w);
+  } else {
+    cvt2<DT>(r.a.x, o[0], o[1]); cvt2<DT>(r.a.y, o[2], o[3]); cvt2<DT>(r.a.z, o[4], o[5]); cvt2<DT>(r.a.w, o[6], o[7]);
+  }
+}
+
+template <int KDT>
+struct PackK {                                   // 24 adaptive-kernel values (8 channels x 3 taps, index c*3+t)
+  uint4 q[KDT == FCVSR_F32 ? 6 : 3];
+};
+
+template <int KDT>
+__device__ __forceinline__ PackK<KDT> ld_k24(const void* base, long long elem) {
+  PackK<KDT> r;
+  if (KDT == FCVSR_F32) {
+    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(base) + elem);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r.q[i] = p[i];
+  } else {
+    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + elem);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) r.q[i] = p[i];
+  }
+  return r;
+}
+
+template <int KDT>
+__device__ __forceinline__ void unpack_k24(const PackK<KDT>& r, float* k) {
+  if (KDT == FCVSR_F32) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      k[4 * i] = __uint_as_float(r.q[i].x); k[4 * i + 1] = __uint_as_float(r.q[i].y);
+      k[4 * i + 2] = __uint_as_float(r.q[i].z); k[4 * i + 3] = __uint_as_float(r.q[i].w);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      cvt2<KDT>(r.q[i].x, k[8 * i], k[8 * i + 1]); cvt2<KDT>(r.q[i].y, k[8 * i + 2], k[8 * i + 3]);
+      cvt2<KDT>(r.q[i].z, k[8 * i + 4], k[8 * i + 5]); cvt2<KDT>(r.q[i].w, k[8 * i + 6], k[8 * i + 7]);
+    }
+  }
+}
+
+template <int ADT>
+__device__ __forceinline__ void st_p8(float* base, long long elem, const float* x) {
+  if (ADT == FCVSR_F32) {
+    *reinterpret_cast<float4*>(base + elem) = make_float4(x[0], x[1], x[2], x[3]);
+    *reinterpret_cast<float4*>(base + elem + 4) = make_float4(x[4], x[5], x[6], x[7]);
+  } else if (ADT == FCVSR_BF16) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 b8;
+    const b8 c = {(__bf16)x[0], (__bf16)x[1], (__bf16)x[2], (__bf16)x[3], (__bf16)x[4], (__bf16)x[5], (__bf16)x[6], (__bf16)x[7]};
+    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + elem) = __builtin_bit_cast(uint4, c);
+  } else {
+    typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+    const h8 c = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3], (_Float16)x[4], (_Float16)x[5], (_Float16)x[6], (_Float16)x[7]};
+    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + elem) = __builtin_bit_cast(uint4, c);
+  }
+}
+
+template <int KDT, int ADT>
+__global__ __launch_bounds__(256) void iac_step64_kernel(View prev, View off, View k1, View fin, float slope, int B, int H,
+                                                         int W, View dst, int tiles_x, int tiles_y) {
+  __shared__ __align__(16) float s_s[kIHY * kIHX * kJC];
+  __shared__ __align__(16) float v_s[kIY * kIHX * kJC];
+  const int tid = threadIdx.x;
+  const int oct = tid & 7, ps = tid >> 3;              // 8-channel group, pixel slot (32 per pass)
+  const int c0 = blockIdx.y * kJC + oct * 8;
+  int t = blockIdx.x;
+  {                                                    // workgroups go round-robin to the 8 XCDs: give each XCD a contiguous
+    const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = t & 7, loc = t >> 3;   // run of tiles so halos hit its L2
+    t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  }
+  const int b = t / (tiles_x * tiles_y);
+  const int t2 = t - b * tiles_x * tiles_y;
+  const int ty0 = (t2 / tiles_x) * kIY, tx0 = (t2 % tiles_x) * kIX;
+
+  // ---- loads that do not depend on the offsets: K1 and feat_in of the lane's two interior pixels, K1 of its halo column ----
+  // interior pixel of pass j: p = j*32 + ps -> (y, x) = (p >> 4, p & 15); halo-column pixel (ps < 8): y = ps >> 1, hx = 0 or 17
+  PackK<KDT> kin[2], khal;
+  Pack8<ADT> fpk[2];
+  const long long kb = (long long)b * k1.sb + c0 * 3;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int p = j * 32 + ps;
+    int gy = ty0 + (p >> 4), gx = tx0 + (p & 15);
+    gy = gy > H - 1 ? H - 1 : gy;
+    gx = gx > W - 1 ? W - 1 : gx;
+    kin[j] = ld_k24<KDT>(k1.p, kb + (long long)gy * k1.sy + (long long)gx * k1.sx);
+    fpk[j] = ld_p8<ADT>(fin.p, (long long)b * fin.sb + (long long)gy * fin.sy + (long long)gx * fin.sx + c0);
+  }
+  {
+    int gy = ty0 + (ps >> 1), gx = tx0 + ((ps & 1) ? kIX : -1);
+    gy = gy > H - 1 ? H - 1 : gy;
+    gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
+    if (ps < 8) khal = ld_k24<KDT>(k1.p, kb + (long long)gy * k1.sy + (long long)gx * k1.sx);
+  }
+
+  // ---- phase 1: s = flow_warp(prev, off) on the halo tile (coordinates clamped = replicate padding of s) -------------
+  // Staged so that the loads batch: all offsets, then all 4 x NP bilinear taps (unconditional: out-of-image taps read a
+  // clamped address with weight 0, which is what the zero padding of flow_warp amounts to), then the arithmetic.
+  const long long pp = (long long)b * prev.sb + c0;
+  constexpr int NP = (kIHY * kIHX + 31) / 32;
+  float ox[NP], oy[NP];
+  int cgx[NP], cgy[NP];
+#pragma unroll
+  for (int it = 0; it < NP; ++it) {
+    int hp = it * 32 + ps;
+    hp = hp < kIHY * kIHX ? hp : kIHY * kIHX - 1;
+    const int hy = hp / kIHX, hx = hp - hy * kIHX;
+    int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+    gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
+    gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
+    const float* op = off.p + (long long)b * off.sb + (long long)gy * off.sy + (long long)gx * off.sx;
+    ox[it] = op[0];
+    oy[it] = op[off.sc];
+    cgx[it] = gx;
+    cgy[it] = gy;
+  }
+  Pack8<ADT> tap[NP][4];
+  float tw[NP][4];
+#pragma unroll
+  for (int it = 0; it < NP; ++it) {
+    const float fx = (float)cgx[it] + ox[it];
+    const float fy = (float)cgy[it] + oy[it];
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float wx1 = fx - x0f, wy1 = fy - y0f;
+    const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const bool sane = (fx > -2.f) && (fx < (float)W + 1.f) && (fy > -2.f) && (fy < (float)H + 1.f);
+    const int x0 = sane ? (int)x0f : -4, y0 = sane ? (int)y0f : -4;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int xi = x0 + dx, yi = y0 + dy;
+        const bool in = xi >= 0 && xi < W && yi >= 0 && yi < H;
+        const int xc = xi < 0 ? 0 : (xi > W - 1 ? W - 1 : xi), yc = yi < 0 ? 0 : (yi > H - 1 ? H - 1 : yi);
+        tw[it][dy * 2 + dx] = in ? (dy ? wy1 : wy0) * (dx ? wx1 : wx0) : 0.f;
+        tap[it][dy * 2 + dx] = ld_p8<ADT>(prev.p, pp + (long long)yc * prev.sy + (long long)xc * prev.sx);
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NP; ++it) {
+    const int hp = it * 32 + ps;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[8];
+      unpack8<ADT>(tap[it][q], v);
+      // an out-of-image tap must contribute exactly 0 even if the clamped sample is Inf/NaN
+      const float w = tw[it][q];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = w != 0.f ? fmaf(v[c], w, acc[c]) : acc[c];
+    }
+    if (hp < kIHY * kIHX) {
+      float* sp = s_s + hp * kJC + oct * 8;
+      *reinterpret_cast<float4*>(sp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<float4*>(sp + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: v[y][hx] = sum_t s[y+t][hx] * K1[y][clamp(hx)][c*3+t] ---------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    int y, hx;
+    if (j < 2) { const int p = j * 32 + ps; y = p >> 4; hx = (p & 15) + 1; }
+    else { y = ps >> 1; hx = (ps & 1) ? kIHX - 1 : 0; }
+    if (j < 2 || ps < 8) {
+      float k[24];
+      unpack_k24<KDT>(j < 2 ? kin[j] : khal, k);
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt) {
+        const float* sp = s_s + ((y + tt) * kIHX + hx) * kJC + oct * 8;
+        const float4 va = *reinterpret_cast<const float4*>(sp), vb = *reinterpret_cast<const float4*>(sp + 4);
+        const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = fmaf(v[c], k[c * 3 + tt], acc[c]);
+      }
+      float* vp = v_s + (y * kIHX + hx) * kJC + oct * 8;
+      *reinterpret_cast<float4*>(vp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<float4*>(vp + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3: out = lrelu( sum_t v[y][x+t] * K1[y][x][c*3+t] + feat_in ) ------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int p = j * 32 + ps;
+    const int y = p >> 4, x = p & 15;
+    const int gy = ty0 + y, gx = tx0 + x;
+    if (gy < H && gx < W) {
+      float k[24], f[8];
+      unpack_k24<KDT>(kin[j], k);
+      unpack8<ADT>(fpk[j], f);
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt) {
+        const float* vp = v_s + (y * kIHX + x + tt) * kJC + oct * 8;
+        const float4 va = *reinterpret_cast<const float4*>(vp), vb = *reinterpret_cast<const float4*>(vp + 4);
+        const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = fmaf(v[c], k[c * 3 + tt], acc[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        acc[c] += f[c];
+        acc[c] = acc[c] >= 0.f ? acc[c] : acc[c] * slope;
+      }
+      st_p8<ADT>(dst.p, (long long)b * dst.sb + (long long)gy * dst.sy + (long long)gx * dst.sx + c0, acc);
+    }
+  }
+}
+
 }  // namespace fcvsr
 
 using namespace fcvsr;
@@ -174,8 +434,17 @@ static bool quad_ok(const fcvsr_view* v, int dt) {
 }
 
 template <int KDT>
-static void launch_iac(int adt, dim3 grid, hipStream_t st, View pv, View ov, View kv, View fv, float slope, int B, int H, int W,
-                       View dv, int tx, int ty) {
+static void launch_iac(int adt, bool wide, dim3 grid, hipStream_t st, View pv, View ov, View kv, View fv, float slope, int B, int H,
+                       int W, View dv, int tx, int ty) {
+  if (wide) {
+    if (adt == FCVSR_F32)
+      hipLaunchKernelGGL((iac_step64_kernel<KDT, FCVSR_F32>), grid, dim3(256), 0, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
+    else if (adt == FCVSR_BF16)
+      hipLaunchKernelGGL((iac_step64_kernel<KDT, FCVSR_BF16>), grid, dim3(256), 0, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
+    else
+      hipLaunchKernelGGL((iac_step64_kernel<KDT, FCVSR_F16>), grid, dim3(256), 0, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
+    return;
+  }
   if (adt == FCVSR_F32)
     hipLaunchKernelGGL((iac_step_kernel<KDT, FCVSR_F32>), grid, dim3(256), 0, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
   else if (adt == FCVSR_BF16)
@@ -198,12 +467,17 @@ extern "C" int fcvsr_iac_step(const fcvsr_view* prev, const fcvsr_view* off, con
   const int g = k1->dtype == FCVSR_F32 ? 4 : 8;   // 16-byte (f32) / 8-byte (16-bit) vector loads of 12-element groups
   FCVSR_CHECK_ARG(((uintptr_t)k1->ptr % 16) == 0 && k1->sx % g == 0 && k1->sy % g == 0 && k1->sb % g == 0, "k1 alignment");
   const int tx = cdiv(W, kIX), ty = cdiv(H, kIY);
-  dim3 grid(B * tx * ty, prev->c / kIC);
+  // 64-channel kernel: 16-byte accesses of 8 channels (features) / 24 kernel values
+  static const bool no_wide = getenv("FCVSR_IAC_WIDE") && atoi(getenv("FCVSR_IAC_WIDE")) == 0;
+  const int fa = adt == FCVSR_F32 ? 4 : 8;
+  auto wide_ok = [&](const fcvsr_view* v) { return ((uintptr_t)v->ptr % 16) == 0 && v->sx % fa == 0 && v->sy % fa == 0 && v->sb % fa == 0; };
+  const bool wide = !no_wide && prev->c % kJC == 0 && wide_ok(prev) && wide_ok(feat_in) && wide_ok(dst);
+  dim3 grid(B * tx * ty, prev->c / (wide ? kJC : kIC));
   hipStream_t st = (hipStream_t)stream;
   const View pv = to_view(*prev), ov = to_view(*off), kv = to_view(*k1), fv = to_view(*feat_in), dv = to_view(*dst);
-  if (k1->dtype == FCVSR_F32) launch_iac<FCVSR_F32>(adt, grid, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
-  else if (k1->dtype == FCVSR_BF16) launch_iac<FCVSR_BF16>(adt, grid, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
-  else launch_iac<FCVSR_F16>(adt, grid, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
+  if (k1->dtype == FCVSR_F32) launch_iac<FCVSR_F32>(adt, wide, grid, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
+  else if (k1->dtype == FCVSR_BF16) launch_iac<FCVSR_BF16>(adt, wide, grid, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
+  else launch_iac<FCVSR_F16>(adt, wide, grid, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

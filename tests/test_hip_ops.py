@@ -223,11 +223,12 @@ def test_corr_warp_sac_vs_oracle():
 
 
 @pytest.mark.parametrize("kdt", ["f32", "bf16", "f16"])
-def test_iac_step_fused_vs_oracle(kdt):
+@pytest.mark.parametrize("Cc", [64, 32])             # 64: the 8-channels-per-lane kernel; 32: the 4-channel one
+def test_iac_step_fused_vs_oracle(kdt, Cc):
     from fcvsr_amd import hip
     from oracle import fcvsr_oracle as O
     L = hip.lib()
-    B, Cc, H, W = 2, 64, 22, 37                      # partial tiles in both directions
+    B, H, W = 2, 22, 37                              # partial tiles in both directions
     f, fin = _rand(B, Cc, H, W, seed=3), _rand(B, Cc, H, W, seed=6)
     off, k1 = _rand(B, 2, H, W, seed=4) * 3.0, _rand(B, 3 * Cc, H, W, seed=5)
     tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[kdt]
@@ -239,6 +240,29 @@ def test_iac_step_fused_vs_oracle(kdt):
                                hip.stream_ptr()), "iac_step")
     ref = F.leaky_relu(O.sac_kernel1_twice(O.warp_bilinear(f, off), k1r) + fin, 0.1)
     assert float((nchw(out) - ref).abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("adt", ["bf16", "f16"])
+@pytest.mark.parametrize("Cc", [64, 32])
+def test_iac_step_16bit_features(adt, Cc):
+    """Features, adaptive kernels and the output stored in the 16-bit activation dtype (arithmetic stays f32): equal to
+    the oracle on the rounded inputs up to the final rounding of the output."""
+    from fcvsr_amd import hip
+    from oracle import fcvsr_oracle as O
+    L = hip.lib()
+    B, H, W = 2, 21, 35
+    tdt = {"bf16": torch.bfloat16, "f16": torch.float16}[adt]
+    f, fin = _rand(B, Cc, H, W, seed=13).to(tdt), _rand(B, Cc, H, W, seed=16).to(tdt)
+    off, k1 = _rand(B, 2, H, W, seed=14) * 3.0, _rand(B, 3 * Cc, H, W, seed=15).to(tdt)
+    fd, find, od, kd = nhwc(f.float()).to(tdt), nhwc(fin.float()).to(tdt), nhwc(off), nhwc(k1.float()).to(tdt)
+    out = torch.empty_like(fd)
+    fv, finv, ov, kv, outv = (hip.view(t) for t in (fd, find, od, kd, out))
+    hip.check(L.fcvsr_iac_step(C.byref(fv), C.byref(ov), C.byref(kv), C.byref(finv), 0.1, B, H, W, C.byref(outv),
+                               hip.stream_ptr()), "iac_step")
+    ref = F.leaky_relu(O.sac_kernel1_twice(O.warp_bilinear(f.float(), off), k1.float()) + fin.float(), 0.1)
+    got = nchw(out.float())
+    eps = 2.0 ** -8 if adt == "bf16" else 2.0 ** -11
+    assert float(((got - ref).abs() / (ref.abs() + 1.0)).max()) < 1.01 * eps
 
 
 def test_flow_warp_known_answer():

@@ -20,14 +20,10 @@
 // Replaces nn.Conv2d(+bias+activation+residual+cat+PixelShuffle) for every stride-1 layer of the path (see fcvsr_hip.h).
 #include <stdlib.h>
 #include "common.h"
+#include "mfma_util.h"
+#include "conv_ws.h"
 
 namespace fcvsr {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 constexpr int kTW = 32, kCK = 64, kLD = kCK + 8;  // tile cols, channel chunk, padded LDS row (halfwords); tile rows = 4*MW
 
@@ -63,25 +59,6 @@ struct MfmaArgs {
   int sub2;            // stride-2 convolution: evaluate at full resolution, keep the even output pixels only
   int dbg;             // ablation switches for profiling builds (FCVSR_MFMA_DBG): 1 skip staging, 2 skip MFMA, 4 skip stores, 8 skip weight loads
 };
-
-template <bool BF16>
-__device__ __forceinline__ uint2 cvt4(float4 v) {
-  if (BF16) {
-    bf16x4_t c = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-    return __builtin_bit_cast(uint2, c);
-  } else {
-    f16x4_t c = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-    return __builtin_bit_cast(uint2, c);
-  }
-}
-
-template <bool BF16>
-__device__ __forceinline__ f32x16_t mfma(uint4 a, uint4 b, f32x16_t c) {
-  if (BF16)
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-}
 
 struct EpiCtx {
   int act, n_res, ps, flat, H, W, b, dst16, dstbf, sub2, cq4;   // dstbf: 16-bit destination is bf16 (may differ from the MFMA dtype)   // cq4 = cout/4 (pixel-shuffle: couts are ordered sub-pixel-major)
@@ -600,39 +577,6 @@ __global__ __launch_bounds__(256, MW == 1 ? (WD ? (NT == 128 ? 2 : 3) : (NT == 1
 // here every per-element index computation is hoisted - halo staging walks (row, col) incrementally with 32-bit offsets and
 // constant LDS strides, the epilogue works on one tile row per wave with loop-invariant bias / channel offsets.
 // =====================================================================================================================
-template <bool BF16>
-__device__ __forceinline__ void cvt16x4_to_f32(uint2 v, float* o) {
-  if (BF16) {
-    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
-  } else {
-    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
-    const h2 a = __builtin_bit_cast(h2, v.x), b = __builtin_bit_cast(h2, v.y);
-    o[0] = (float)a[0]; o[1] = (float)a[1]; o[2] = (float)b[0]; o[3] = (float)b[1];
-  }
-}
-
-// residual load of NV (4 or 8) consecutive channels at element offset `off` of a view base (f32 or 16-bit storage)
-template <bool BF16, int NV>
-__device__ __forceinline__ void load_res(const float* base, long long off, bool r16, float* o) {
-  if (r16) {
-    const uint16_t* p = reinterpret_cast<const uint16_t*>(base) + off;
-    if (NV == 8) {
-      const uint4 v = *reinterpret_cast<const uint4*>(p);
-      cvt16x4_to_f32<BF16>(make_uint2(v.x, v.y), o);
-      cvt16x4_to_f32<BF16>(make_uint2(v.z, v.w), o + 4);
-    } else {
-      cvt16x4_to_f32<BF16>(*reinterpret_cast<const uint2*>(p), o);
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < NV; k += 4) {
-      const float4 t = *reinterpret_cast<const float4*>(base + off + k);
-      o[k] = t.x; o[k + 1] = t.y; o[k + 2] = t.z; o[k + 3] = t.w;
-    }
-  }
-}
-
 template <bool BF16, int NT, bool SRC16, bool DST16>
 __global__ __launch_bounds__(256, NT == 128 ? 2 : 4) void conv3_lean_kernel(MfmaArgs a) {
   constexpr int HWD = kTW + 2, NHP = 6 * HWD;          // 6 x 34 halo pixels
@@ -1396,6 +1340,56 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
     e = (mma_dtype == FCVSR_BF16) ? dispatch_lean1<true>(a, nt, tiles, st) : dispatch_lean1<false>(a, nt, tiles, st);
     if (e != hipSuccess) {
       set_error("fcvsr_conv2d_mfma: launch failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    return 0;
+  }
+  // weight-stationary persistent kernel (conv_ws.hip): 16-bit dense source of exactly 64 channels, cout 64/128/256,
+  // channel-contiguous destination and residuals, no ContextBlock fusion
+  bool ws = lean && a.src16 && conv3_ws_supports(cin, d0.cout) && d0.gc_wmask == nullptr;
+  for (int g = 0; g < n_groups && ws; ++g) {
+    const fcvsr_conv_desc& d = descs[g];
+    ws = ws && d.dst.sc == 1 && d.dst.sx % 4 == 0;
+    for (int q = 0; q < d.n_res; ++q) ws = ws && d.res[q].sc == 1;
+  }
+  {
+    // Experimental, off by default: measured 0.75-0.9x of the lean kernel on the path's shapes ("weight-stationary
+    // experiment") - two waves per SIMD cannot hide the epilogue / staging phases that 4-5 co-resident lean workgroups overlap.
+    const char* e3 = getenv("FCVSR_MFMA_WS");
+    if (!e3 || atoi(e3) == 0) ws = false;
+  }
+  if (ws) {
+    static void* zeros = nullptr;
+    if (!zeros) {
+      hipError_t ez = hipMalloc(&zeros, 256);
+      if (ez == hipSuccess) ez = hipMemset(zeros, 0, 256);
+      if (ez != hipSuccess) {
+        zeros = nullptr;
+        set_error("fcvsr_conv2d_mfma: zero page allocation failed: %s", hipGetErrorString(ez));
+        return (int)ez;
+      }
+    }
+    WsArgs wa;
+    wa.n_groups = n_groups;
+    int wtiles = 0;
+    for (int g = 0; g < 3; ++g) {
+      const MGroup& G = a.g[g < n_groups ? g : 0];
+      WsGroup& Wg = wa.g[g];
+      Wg.src = G.src[0]; Wg.res[0] = G.res[0]; Wg.res[1] = G.res[1]; Wg.dst = G.dst; Wg.gc_partial = nullptr;
+      Wg.B = G.B; Wg.H = G.H; Wg.W = G.W;
+      Wg.tiles_x = cdiv(G.W, 32);
+      Wg.tiles_y = cdiv(G.H, 4);
+      Wg.tile_begin = wtiles;
+      if (g < n_groups) wtiles += G.B * Wg.tiles_x * Wg.tiles_y;
+    }
+    wa.total_tiles = wtiles;
+    wa.cin = cin; wa.cout = d0.cout; wa.cout_pad = d0.cout_pad; wa.cin_pad = a.cin_pad;
+    wa.w = a.w; wa.bias = a.bias; wa.act = a.act; wa.slope = a.slope; wa.slope_ptr = a.slope_ptr;
+    wa.rs[0] = a.rs[0]; wa.rs[1] = a.rs[1]; wa.n_res = a.n_res; wa.res16 = a.res16; wa.zeros = zeros;
+    { const char* wd_ = getenv("FCVSR_WS_DBG"); wa.dbg = wd_ ? atoi(wd_) : 0; }
+    e = launch_conv3_ws(wa, mma_dtype == FCVSR_BF16, a.dst16 != 0, st);
+    if (e != hipSuccess) {
+      set_error("fcvsr_conv2d_mfma: weight-stationary launch failed: %s", hipGetErrorString(e));
       return (int)e;
     }
     return 0;

@@ -279,3 +279,32 @@ def test_flow_warp_known_answer():
     ref = torch.zeros_like(x)
     ref[:, :, 1:, 1:] = x[:, :, :-1, :-1]
     assert float((nchw(out) - ref).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("cout,d16,nres,levels", [(64, True, 0, [(21, 37)]), (64, False, 2, [(21, 37), (11, 19), (6, 10)]),
+                                                  (128, True, 1, [(20, 70)]), (256, True, 0, [(9, 33)])])
+def test_conv_weight_stationary_matches_lean(cout, d16, nres, levels, monkeypatch):
+    """The opt-in weight-stationary 3x3 kernel (FCVSR_MFMA_WS=1, conv_ws.hip) accumulates in the same order as the lean
+    kernel, so the two must agree bit for bit (partial tiles, three grouped levels, residuals, both destination types)."""
+    from fcvsr_amd import hip
+    dt = torch.bfloat16
+    g0 = torch.Generator().manual_seed(cout + nres)
+    w = torch.randn(cout, 64, 3, 3, generator=g0) / 24.0
+    bias = torch.randn(cout, generator=g0).cuda()
+    wp = hip.pack_conv_weight_mfma(w.cuda(), dt)
+    groups = []
+    for (H, W) in levels:
+        x = torch.randn(2, H, W, 64, generator=g0).cuda().to(dt)
+        y = torch.empty(2, H, W, cout, device="cuda", dtype=dt if d16 else torch.float32)
+        res = [torch.randn(2, H, W, cout, generator=g0).cuda().to(dt) for _ in range(nres)]
+        groups.append(dict(srcs=[x], dst=y, res=res))
+    outs = []
+    for ws in ("0", "1"):
+        monkeypatch.setenv("FCVSR_MFMA_WS", ws)
+        for g in groups:
+            g["dst"].zero_()
+        hip.conv2d_mfma(groups, wp, 3, cout, hip.BF16, bias=bias, act=hip.ACT_LEAKY, slope=0.1, res_scale=[1.0, -0.5][:nres])
+        torch.cuda.synchronize()
+        outs.append([g["dst"].clone() for g in groups])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -10,17 +10,17 @@ namespace fcvsr {
 // corr[c=i*n+j][y][x] = I_p[y+j-r][x+i-r] (zero outside the C/2 x 2 image), I_p = the C consecutive floats at flat
 // offset p*C of the NCHW-contiguous product buffer P = x1f*x2f/sqrt(C)  (raw .view() reinterpretation in the reference).
 __global__ void corr_lookup_kernel(const float* x1f, const float* x2f, long long ps, int B, int H, int Wf, int C,
-                                   int radius, View dst, float norm_div) {
+                                   int radius, int xw, View dst, float norm_div) {
   const int n = 2 * radius + 1;
   const int nn = n * n;
-  const long long total = (long long)B * H * Wf * dst.c;
+  const long long total = (long long)B * H * xw * dst.c;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   const int c = (int)(t % dst.c);
   const long long pixg = t / dst.c;
-  const int x = (int)(pixg % Wf);
-  const int y = (int)((pixg / Wf) % H);
-  const int b = (int)(pixg / ((long long)Wf * H));
+  const int x = (int)(pixg % xw);
+  const int y = (int)((pixg / xw) % H);
+  const int b = (int)(pixg / ((long long)xw * H));
   float v = 0.f;
   if (c < nn) {
     const int i = c / n, j = c % n;
@@ -172,13 +172,14 @@ __global__ void sac_kernel(View s, View k1, View fin, float slope, int B, int H,
 using namespace fcvsr;
 
 extern "C" int fcvsr_corr_lookup(const float* x1f, const float* x2f, int64_t pix_stride, int B, int H, int Wf, int C,
-                                 int radius, const fcvsr_view* dst, void* stream) {
+                                 int radius, int x_count, const fcvsr_view* dst, void* stream) {
   FCVSR_CHECK_ARG(x1f && x2f && dst && dst->ptr, "null pointer");
   FCVSR_CHECK_ARG(B > 0 && H > 0 && Wf > 0 && C > 0 && C % 2 == 0 && radius >= 0 && pix_stride >= C, "bad sizes");
-  FCVSR_CHECK_ARG(dst->c >= (2 * radius + 1) * (2 * radius + 1), "dst needs >= (2r+1)^2 channels");
-  const long long total = (long long)B * H * Wf * dst->c;
+  FCVSR_CHECK_ARG(dst->c >= (2 * radius + 1) * (2 * radius + 1) && dst->dtype == FCVSR_F32, "dst: f32, >= (2r+1)^2 channels");
+  FCVSR_CHECK_ARG(x_count > 0 && x_count <= Wf, "x_count must be in [1, Wf]");
+  const long long total = (long long)B * H * x_count * dst->c;
   hipLaunchKernelGGL(corr_lookup_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x1f, x2f,
-                     (long long)pix_stride, B, H, Wf, C, radius, to_view(*dst), sqrtf((float)C));
+                     (long long)pix_stride, B, H, Wf, C, radius, x_count, to_view(*dst), sqrtf((float)C));
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

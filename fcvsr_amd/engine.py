@@ -107,12 +107,14 @@ class Engine:
             return wp, None
         return w, (b.detach() if b is not None else None)
 
-    def _weights(self, name, kind, ps=False, rows=None):
+    def _weights(self, name, kind, ps=False, rows=None, cols=None):
         """kind: 'direct' (f32 [taps][cin][cout16]) | torch.bfloat16 | torch.float16 (MFMA layout; with ps=True the rows
         are in the sub-pixel-major order the MFMA kernel's pixel-shuffle epilogue expects)."""
-        key = (name, kind, ps, rows)
+        key = (name, kind, ps, rows, cols)
         if key not in self._packed:
             w, b = self._logical_weight(name)
+            if cols is not None:                      # a slice of the input channels (a layer applied to part of a concat)
+                w = w[:, cols[0]:cols[1]]
             if rows is not None:                      # a slice of the output channels (feat_extract is run per frame group)
                 w = w[rows[0]:rows[1]]
                 b = b[rows[0]:rows[1]].contiguous() if b is not None else None
@@ -152,13 +154,14 @@ class Engine:
 
     # ---------------------------------------------------------------------------------------------- helpers
     def _conv(self, name, srcs, dst, *, stride=1, act=ACT_NONE, slope=0.0, slope_t=None, res=(), res_scale=(),
-              ps=False, freq=False, direct=False, force_f16=False, rows=None):
+              ps=False, freq=False, direct=False, force_f16=False, rows=None, cols=None):
         self._convg(name, [dict(srcs=srcs, dst=dst, res=res, ps=ps)], stride=stride, act=act, slope=slope,
-                    slope_t=slope_t, res_scale=res_scale, ps=ps, freq=freq, direct=direct, force_f16=force_f16, rows=rows)
+                    slope_t=slope_t, res_scale=res_scale, ps=ps, freq=freq, direct=direct, force_f16=force_f16, rows=rows,
+                    cols=cols)
         return dst
 
     def _convg(self, name, groups, *, stride=1, act=ACT_NONE, slope=0.0, slope_t=None, res_scale=(), ps=False,
-               freq=False, direct=False, force_f16=False, gc_wmask=None, rows=None):
+               freq=False, direct=False, force_f16=False, gc_wmask=None, rows=None, cols=None):
         """One conv layer applied to 1..3 tensors that share its weights (pyramid levels): a single grouped MFMA launch in
         the 16-bit modes, per-tensor exact-f32 direct launches otherwise."""
         ksz = self._par[name + ".weight"].shape[-1]
@@ -171,12 +174,12 @@ class Engine:
             dt = torch.bfloat16 if (self.precision == "bf16" or freq) else torch.float16
             if force_f16:      # image-domain input in [0,1]: f16's 11-bit significand keeps 8-bit pixels exact
                 dt = torch.float16
-            w, b, cout, _ = self._weights(name, dt, ps, rows)
+            w, b, cout, _ = self._weights(name, dt, ps, rows, cols)
             hip.conv2d_mfma(groups, w, ksz, cout, hip.BF16 if dt == torch.bfloat16 else hip.F16, stride=stride, bias=b, act=act,
                             slope=slope, slope_t=slope_t, res_scale=res_scale, pixel_shuffle=ps, gc_wmask=gc_wmask,
                             name=name)
             return True
-        w, b, cout, _ = self._weights(name, "direct", False, rows)
+        w, b, cout, _ = self._weights(name, "direct", False, rows, cols)
         for g in groups:
             hip.conv2d(g["srcs"], w, ksz, cout, g["dst"], bias=b, stride=stride, act=act, slope=slope, slope_t=slope_t,
                        res=g.get("res", ()), res_scale=res_scale, pixel_shuffle=ps, name=name)
@@ -228,8 +231,9 @@ class Engine:
         x1f, x2f, x3f = spec[..., :2 * n], spec[..., 2 * n:4 * n], spec[..., 4 * n:]
 
         # offset spectra: (x?f - x2f) + convfuse(cat[x?f, x2f]); batch index = dir*B + b
-        off = self._new(dev, 2 * B, H, Wf, 2 * n)
         fdt = self._adt(freq=True)
+        # the offset spectra feed only convcorr.0: stored in its operand dtype (bit-identical results, half the bytes)
+        off = self._new(dev, 2 * B, H, Wf, 2 * n, dtype=fdt)
         t0 = self._new(dev, B, H, Wf, 2 * n, dtype=fdt)
         t1 = self._new(dev, B, H, Wf, 2 * n, dtype=fdt)
         for d, xa in enumerate((x1f, x3f)):
@@ -241,15 +245,33 @@ class Engine:
         self._conv("MGAA.convcrt.0", [x2f], s0, act=ACT_RELU, freq=True)
         self._conv("MGAA.convcrt.2", [s0], sim, freq=True)
 
-        corr = self._new(dev, B, H, Wf, 84)                      # 81 live channels + 3 zero pad (16-byte pixels)
-        cv = view(corr)
-        check(L.fcvsr_corr_lookup(x1f.data_ptr(), x2f.data_ptr(), 6 * n, B, H, Wf, 2 * n, 4, C.byref(cv), st),
-              "fcvsr_corr_lookup")
         c0 = self._new(dev, 2 * B, H, Wf, n, dtype=fdt)
         c1 = self._new(dev, 2 * B, H, Wf, n, dtype=fdt)
         off4 = self._new(dev, 2 * B, H, Wf, 4)
-        for d in range(2):
-            self._conv("MGAA.convcorr.0", [off[d * B:(d + 1) * B], corr], c0[d * B:(d + 1) * B], act=ACT_RELU, freq=True)
+        if fdt == torch.float32:
+            corr = self._new(dev, B, H, Wf, 84)                  # 81 live channels + 3 zero pad (16-byte pixels)
+            cv = view(corr)
+            check(L.fcvsr_corr_lookup(x1f.data_ptr(), x2f.data_ptr(), 6 * n, B, H, Wf, 2 * n, 4, Wf, C.byref(cv), st),
+                  "fcvsr_corr_lookup")
+            for d in range(2):
+                self._conv("MGAA.convcorr.0", [off[d * B:(d + 1) * B], corr], c0[d * B:(d + 1) * B], act=ACT_RELU, freq=True)
+        else:
+            # The CorrBlock lookup is identically zero beyond column radius+1 = 5 (it samples a 2-pixel-wide image,
+            # CVSR_freq.py:1318-1337), so its 81 input channels contribute exact zeros to convcorr.0 everywhere else:
+            # one launch over both directions on the offset spectra alone, then the narrow strip x < 8 is recomputed with
+            # the lookup channels and pasted over - the same sums as the full concat (zeros add nothing to an f32 chain).
+            self._conv("MGAA.convcorr.0", [off], c0, act=ACT_RELU, freq=True, cols=(0, 2 * n))
+            xs = min(Wf, 8)
+            corr = self._new(dev, B, H, xs, 84)
+            cv = view(corr)
+            check(L.fcvsr_corr_lookup(x1f.data_ptr(), x2f.data_ptr(), 6 * n, B, H, Wf, 2 * n, 4, xs, C.byref(cv), st),
+                  "fcvsr_corr_lookup")
+            off_s = off[:, :, :xs].to(torch.float32, memory_format=torch.contiguous_format)   # (2B,H,xs,2n) strip copy
+            c0_s = self._new(dev, 2 * B, H, xs, n, dtype=fdt)
+            for d in range(2):
+                self._conv("MGAA.convcorr.0", [off_s[d * B:(d + 1) * B], corr], c0_s[d * B:(d + 1) * B], act=ACT_RELU,
+                           freq=True)
+            c0[:, :, :xs].copy_(c0_s)
         self._conv("MGAA.convcorr.2", [c0], c1, act=ACT_RELU, freq=True)
         self._conv("MGAA.convcorr.4", [c1], off4, freq=True)
 

@@ -105,9 +105,11 @@ int fcvsr_irfft2(const float* spec, int64_t pix_stride, int im_off, int re_off, 
 
 /* ---- MGAAbk pieces (CVSR_freq.py:1365-1547) ---------------------------------------------------------------- */
 /* CorrBlock lookup on the integer grid (:1279-1337): x1f,x2f NHWC (B,H,Wf,C) with pixel stride
- * pix_stride (floats); dst (B,H,Wf,>=81); channels beyond (2r+1)^2 are zero-filled */
+ * pix_stride (floats); dst (B,H,x_count,>=81); channels beyond (2r+1)^2 are zero-filled.  Only the first x_count
+ * columns are produced (x_count = Wf for the whole map): the lookup is identically zero for x > radius+1, because the
+ * reference samples a (C/2 x 2)-pixel image (column index x+i-r must be 0 or 1), so callers may evaluate a strip only */
 int fcvsr_corr_lookup(const float* x1f, const float* x2f, int64_t pix_stride, int B, int H, int Wf, int C, int radius,
-                      const fcvsr_view* dst, void* stream);
+                      int x_count, const fcvsr_view* dst, void* stream);
 /* per-(b,c) sums over (y,x) of a view, deterministic two-stage: out[b][c] (f32).  scratch: B*nblk*C floats */
 int fcvsr_channel_sum(const fcvsr_view* src, int B, int H, int W, float* out, float* scratch, int64_t scratch_elems,
                       void* stream);

@@ -203,10 +203,18 @@ def test_corr_warp_sac_vs_oracle():
     dst = torch.empty(B, H, Wf, 84, device="cuda")
     dv = hip.view(dst)
     ad, bd = nhwc(a), nhwc(b)      # keep the device tensors alive while the kernel runs
-    hip.check(L.fcvsr_corr_lookup(ad.data_ptr(), bd.data_ptr(), C2, B, H, Wf, C2, 4, C.byref(dv), st), "corr")
+    hip.check(L.fcvsr_corr_lookup(ad.data_ptr(), bd.data_ptr(), C2, B, H, Wf, C2, 4, Wf, C.byref(dv), st), "corr")
     got = nchw(dst)
     assert torch.equal(got[:, 81:], torch.zeros_like(got[:, 81:]))
-    assert float((got[:, :81] - O.corr_lookup(a, b)).abs().max()) < 1e-6
+    ref = O.corr_lookup(a, b)
+    assert float((got[:, :81] - ref).abs().max()) < 1e-6
+    # the lookup vanishes beyond column radius+1 (the property the engine's strip evaluation rests on) ...
+    assert torch.equal(ref[..., 6:], torch.zeros_like(ref[..., 6:]))
+    # ... and a strip call (x_count < Wf) reproduces the leading columns of the full map
+    strip = torch.empty(B, H, 8, 84, device="cuda")
+    sv = hip.view(strip)
+    hip.check(L.fcvsr_corr_lookup(ad.data_ptr(), bd.data_ptr(), C2, B, H, Wf, C2, 4, 8, C.byref(sv), st), "corr strip")
+    assert torch.equal(strip, dst[:, :, :8])
     # warp + SAC
     B, Cc, H, W = 1, 64, 24, 40
     f, off, k1 = _rand(B, Cc, H, W, seed=3), _rand(B, 2, H, W, seed=4) * 3.0, _rand(B, 3 * Cc, H, W, seed=5)

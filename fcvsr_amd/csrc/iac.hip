@@ -265,9 +265,24 @@ __device__ __forceinline__ void st_p8(float* base, long long elem, const float* 
   }
 }
 
-template <int KDT, int ADT>
-__global__ __launch_bounds__(256) void iac_step64_kernel(View prev, View off, View k1, View fin, float slope, int B, int H,
-                                                         int W, View dst, int tiles_x, int tiles_y) {
+struct IacDir {
+  View prev, off, fin, dst;
+};
+struct IacArgs {
+  IacDir d[2];            // forward / backward alignment direction (ND = 1 uses d[0] only)
+  View k1;
+  float slope;
+  int B, H, W, tiles_x, tiles_y;
+};
+
+// ND = 2: both alignment directions of one IAC iteration in one launch.  They use the SAME adaptive kernels
+// (reference :1524-1545 passes Pred_K to IAC for the forward and the backward group alike), so K1 - half of the bytes
+// a step reads - is fetched once and serves both.
+template <int KDT, int ADT, int ND>
+__global__ __launch_bounds__(256) void iac_step64_kernel(IacArgs a) {
+  const View k1 = a.k1;
+  const float slope = a.slope;
+  const int H = a.H, W = a.W, tiles_x = a.tiles_x, tiles_y = a.tiles_y;
   __shared__ __align__(16) float s_s[kIHY * kIHX * kJC];
   __shared__ __align__(16) float v_s[kIY * kIHX * kJC];
   const int tid = threadIdx.x;
@@ -285,7 +300,6 @@ __global__ __launch_bounds__(256) void iac_step64_kernel(View prev, View off, Vi
   // ---- loads that do not depend on the offsets: K1 and feat_in of the lane's two interior pixels, K1 of its halo column ----
   // interior pixel of pass j: p = j*32 + ps -> (y, x) = (p >> 4, p & 15); halo-column pixel (ps < 8): y = ps >> 1, hx = 0 or 17
   PackK<KDT> kin[2], khal;
-  Pack8<ADT> fpk[2];
   const long long kb = (long long)b * k1.sb + c0 * 3;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -294,7 +308,6 @@ __global__ __launch_bounds__(256) void iac_step64_kernel(View prev, View off, Vi
     gy = gy > H - 1 ? H - 1 : gy;
     gx = gx > W - 1 ? W - 1 : gx;
     kin[j] = ld_k24<KDT>(k1.p, kb + (long long)gy * k1.sy + (long long)gx * k1.sx);
-    fpk[j] = ld_p8<ADT>(fin.p, (long long)b * fin.sb + (long long)gy * fin.sy + (long long)gx * fin.sx + c0);
   }
   {
     int gy = ty0 + (ps >> 1), gx = tx0 + ((ps & 1) ? kIX : -1);
@@ -303,6 +316,18 @@ __global__ __launch_bounds__(256) void iac_step64_kernel(View prev, View off, Vi
     if (ps < 8) khal = ld_k24<KDT>(k1.p, kb + (long long)gy * k1.sy + (long long)gx * k1.sx);
   }
 
+#pragma unroll
+  for (int dir = 0; dir < ND; ++dir) {
+  const View prev = a.d[dir].prev, off = a.d[dir].off, fin = a.d[dir].fin, dst = a.d[dir].dst;
+  Pack8<ADT> fpk[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int p = j * 32 + ps;
+    int gy = ty0 + (p >> 4), gx = tx0 + (p & 15);
+    gy = gy > H - 1 ? H - 1 : gy;
+    gx = gx > W - 1 ? W - 1 : gx;
+    fpk[j] = ld_p8<ADT>(fin.p, (long long)b * fin.sb + (long long)gy * fin.sy + (long long)gx * fin.sx + c0);
+  }
   // ---- phase 1: s = flow_warp(prev, off) on the halo tile (coordinates clamped = replicate padding of s) -------------
   // Staged so that the loads batch: all offsets, then all 4 x NP bilinear taps (unconditional: out-of-image taps read a
   // clamped address with weight 0, which is what the zero padding of flow_warp amounts to), then the arithmetic.
@@ -420,6 +445,7 @@ __global__ __launch_bounds__(256) void iac_step64_kernel(View prev, View off, Vi
       st_p8<ADT>(dst.p, (long long)b * dst.sb + (long long)gy * dst.sy + (long long)gx * dst.sx + c0, acc);
     }
   }
+  }   // direction
 }
 
 }  // namespace fcvsr
@@ -433,16 +459,22 @@ static bool quad_ok(const fcvsr_view* v, int dt) {
   return v->sx % g == 0 && v->sy % g == 0 && v->sb % g == 0 && ((uintptr_t)v->ptr % al) == 0;
 }
 
+template <int KDT, int ND>
+static void launch_iac64(int adt, dim3 grid, hipStream_t st, const IacArgs& a) {
+  if (adt == FCVSR_F32) hipLaunchKernelGGL((iac_step64_kernel<KDT, FCVSR_F32, ND>), grid, dim3(256), 0, st, a);
+  else if (adt == FCVSR_BF16) hipLaunchKernelGGL((iac_step64_kernel<KDT, FCVSR_BF16, ND>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((iac_step64_kernel<KDT, FCVSR_F16, ND>), grid, dim3(256), 0, st, a);
+}
+
 template <int KDT>
 static void launch_iac(int adt, bool wide, dim3 grid, hipStream_t st, View pv, View ov, View kv, View fv, float slope, int B, int H,
                        int W, View dv, int tx, int ty) {
   if (wide) {
-    if (adt == FCVSR_F32)
-      hipLaunchKernelGGL((iac_step64_kernel<KDT, FCVSR_F32>), grid, dim3(256), 0, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
-    else if (adt == FCVSR_BF16)
-      hipLaunchKernelGGL((iac_step64_kernel<KDT, FCVSR_BF16>), grid, dim3(256), 0, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
-    else
-      hipLaunchKernelGGL((iac_step64_kernel<KDT, FCVSR_F16>), grid, dim3(256), 0, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
+    IacArgs a;
+    a.d[0].prev = pv; a.d[0].off = ov; a.d[0].fin = fv; a.d[0].dst = dv;
+    a.d[1] = a.d[0];
+    a.k1 = kv; a.slope = slope; a.B = B; a.H = H; a.W = W; a.tiles_x = tx; a.tiles_y = ty;
+    launch_iac64<KDT, 1>(adt, grid, st, a);
     return;
   }
   if (adt == FCVSR_F32)
@@ -478,6 +510,43 @@ extern "C" int fcvsr_iac_step(const fcvsr_view* prev, const fcvsr_view* off, con
   if (k1->dtype == FCVSR_F32) launch_iac<FCVSR_F32>(adt, wide, grid, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
   else if (k1->dtype == FCVSR_BF16) launch_iac<FCVSR_BF16>(adt, wide, grid, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
   else launch_iac<FCVSR_F16>(adt, wide, grid, st, pv, ov, kv, fv, slope, B, H, W, dv, tx, ty);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fcvsr_iac_step2(const fcvsr_view* prev, const fcvsr_view* off, const fcvsr_view* k1, const fcvsr_view* feat_in,
+                               float slope, int B, int H, int W, const fcvsr_view* dst, void* stream) {
+  FCVSR_CHECK_ARG(prev && off && k1 && feat_in && dst && prev[0].ptr, "null argument");
+  const int adt = prev[0].dtype;
+  FCVSR_CHECK_ARG(adt == FCVSR_F32 || adt == FCVSR_BF16 || adt == FCVSR_F16, "bad feature dtype");
+  const int fa = adt == FCVSR_F32 ? 4 : 8;
+  for (int d = 0; d < 2; ++d) {
+    FCVSR_CHECK_ARG(quad_ok(&prev[d], adt) && quad_ok(&feat_in[d], adt) && quad_ok(&dst[d], adt),
+                    "prev/feat_in/dst: same dtype, channel-contiguous, aligned");
+    FCVSR_CHECK_ARG(off[d].ptr && off[d].c >= 2 && off[d].dtype == FCVSR_F32, "off needs 2 f32 channels");
+    FCVSR_CHECK_ARG(prev[d].c % kJC == 0 && prev[d].c == prev[0].c && prev[d].c == dst[d].c && prev[d].c == feat_in[d].c,
+                    "C must be a multiple of 64 and alike for both directions");
+    const fcvsr_view* vs[3] = {&prev[d], &feat_in[d], &dst[d]};
+    for (const fcvsr_view* v : vs)
+      FCVSR_CHECK_ARG(((uintptr_t)v->ptr % 16) == 0 && v->sx % fa == 0 && v->sy % fa == 0 && v->sb % fa == 0,
+                      "16-byte aligned feature views");
+  }
+  FCVSR_CHECK_ARG(k1->ptr && k1->sc == 1 && k1->c == 3 * prev[0].c, "k1 must have 3*C contiguous channels");
+  FCVSR_CHECK_ARG(B > 0 && H > 0 && W > 0, "bad sizes");
+  const int g = k1->dtype == FCVSR_F32 ? 4 : 8;
+  FCVSR_CHECK_ARG(((uintptr_t)k1->ptr % 16) == 0 && k1->sx % g == 0 && k1->sy % g == 0 && k1->sb % g == 0, "k1 alignment");
+  const int tx = cdiv(W, kIX), ty = cdiv(H, kIY);
+  dim3 grid(B * tx * ty, prev[0].c / kJC);
+  IacArgs a;
+  for (int d = 0; d < 2; ++d) {
+    a.d[d].prev = to_view(prev[d]); a.d[d].off = to_view(off[d]); a.d[d].fin = to_view(feat_in[d]); a.d[d].dst = to_view(dst[d]);
+  }
+  a.k1 = to_view(*k1); a.slope = slope; a.B = B; a.H = H; a.W = W; a.tiles_x = tx; a.tiles_y = ty;
+  hipStream_t st = (hipStream_t)stream;
+  if (k1->dtype == FCVSR_F32) launch_iac64<FCVSR_F32, 2>(adt, grid, st, a);
+  else if (k1->dtype == FCVSR_BF16) launch_iac64<FCVSR_BF16, 2>(adt, grid, st, a);
+  else if (k1->dtype == FCVSR_F16) launch_iac64<FCVSR_F16, 2>(adt, grid, st, a);
+  else FCVSR_CHECK_ARG(false, "bad k1 dtype");
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

@@ -310,25 +310,43 @@ class Engine:
                 raise RuntimeError("16-bit activations need the fused IAC kernel (n_features % 32 == 0)")
             s = self._new(dev, B, H, W, n)
             vbuf = self._new(dev, B, H, W, n)
-        for d, fin in enumerate((x1, x3)):
-            cur = fin
-            fv = view(fin)
+        if fused_iac and n % 64 == 0:
+            # both directions of an iteration in one launch: they share the adaptive kernels, which are read once
+            ping2 = [self._new(dev, B, H, W, n, dtype=fdt_act), self._new(dev, B, H, W, n, dtype=fdt_act)]
+            V2 = hip.View * 2
+            cur = [x1, x3]
+            fins = V2(view(x1), view(x3))
             for i in range(A):
-                g = d * A + i
-                o_v = view(offsets[..., 2 * g:2 * g + 2])
                 k_v = view(K[..., i * 3 * n:(i + 1) * 3 * n])
-                dst = al[..., d * n:(d + 1) * n] if i == A - 1 else ping[i % 2]
-                cur_v, d_v = view(cur), view(dst)
-                if fused_iac:
-                    check(L.fcvsr_iac_step(C.byref(cur_v), C.byref(o_v), C.byref(k_v), C.byref(fv), 0.1, B, H, W,
-                                           C.byref(d_v), st), "fcvsr_iac_step")
+                if i == A - 1:
+                    dsts = [al[..., :n], al[..., n:]]
                 else:
-                    s_v, v_v = view(s), view(vbuf)
-                    check(L.fcvsr_warp(C.byref(cur_v), C.byref(o_v), B, H, W, C.byref(s_v), st), "fcvsr_warp")
-                    check(L.fcvsr_sac_v(C.byref(s_v), C.byref(k_v), B, H, W, C.byref(v_v), st), "fcvsr_sac_v")
-                    check(L.fcvsr_sac_h(C.byref(v_v), C.byref(k_v), C.byref(fv), 0.1, B, H, W, C.byref(d_v), st),
-                          "fcvsr_sac_h")
-                cur = dst
+                    dsts = [ping[i % 2], ping2[i % 2]]
+                prevs = V2(view(cur[0]), view(cur[1]))
+                offs = V2(view(offsets[..., 2 * i:2 * i + 2]), view(offsets[..., 2 * (A + i):2 * (A + i) + 2]))
+                dv2 = V2(view(dsts[0]), view(dsts[1]))
+                check(L.fcvsr_iac_step2(prevs, offs, C.byref(k_v), fins, 0.1, B, H, W, dv2, st), "fcvsr_iac_step2")
+                cur = dsts
+        else:
+            for d, fin in enumerate((x1, x3)):
+                cur = fin
+                fv = view(fin)
+                for i in range(A):
+                    g = d * A + i
+                    o_v = view(offsets[..., 2 * g:2 * g + 2])
+                    k_v = view(K[..., i * 3 * n:(i + 1) * 3 * n])
+                    dst = al[..., d * n:(d + 1) * n] if i == A - 1 else ping[i % 2]
+                    cur_v, d_v = view(cur), view(dst)
+                    if fused_iac:
+                        check(L.fcvsr_iac_step(C.byref(cur_v), C.byref(o_v), C.byref(k_v), C.byref(fv), 0.1, B, H, W,
+                                               C.byref(d_v), st), "fcvsr_iac_step")
+                    else:
+                        s_v, v_v = view(s), view(vbuf)
+                        check(L.fcvsr_warp(C.byref(cur_v), C.byref(o_v), B, H, W, C.byref(s_v), st), "fcvsr_warp")
+                        check(L.fcvsr_sac_v(C.byref(s_v), C.byref(k_v), B, H, W, C.byref(v_v), st), "fcvsr_sac_v")
+                        check(L.fcvsr_sac_h(C.byref(v_v), C.byref(k_v), C.byref(fv), 0.1, B, H, W, C.byref(d_v), st),
+                              "fcvsr_sac_h")
+                    cur = dst
         out = self._new(dev, B, H, W, n, dtype=fdt_act)
         self._conv("MGAA.conv3", [al], out, res=[x2])
         if self.taps is not None:

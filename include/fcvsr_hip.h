@@ -134,6 +134,10 @@ int fcvsr_sac_h(const fcvsr_view* v, const fcvsr_view* k1, const fcvsr_view* fea
  * off f32.  C % 32 == 0. */
 int fcvsr_iac_step(const fcvsr_view* prev, const fcvsr_view* off, const fcvsr_view* k1, const fcvsr_view* feat_in,
                    float slope, int B, int H, int W, const fcvsr_view* dst, void* stream);
+/* The same iteration for BOTH alignment directions in one launch: prev, off, feat_in and dst point at arrays of 2 views
+ * (forward, backward); the two directions share k1 (:1524-1545), which is then read once.  C % 64 == 0. */
+int fcvsr_iac_step2(const fcvsr_view* prev, const fcvsr_view* off, const fcvsr_view* k1, const fcvsr_view* feat_in,
+                    float slope, int B, int H, int W, const fcvsr_view* dst, void* stream);
 
 /* ---- MultiFreq_Refinment pieces (CVSR_freq.py:2104-2133, :2201-2254) ---------------------------------------- */
 /* DivEnh expressions, i==0 (first=1): t=f-mean_f; e1=0.2*a*t*f+b*f.  i>0: t=f-s_f+0.2*s_o; e1 as above;

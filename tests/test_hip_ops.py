@@ -316,3 +316,32 @@ def test_conv_weight_stationary_matches_lean(cout, d16, nres, levels, monkeypatc
         outs.append([g["dst"].clone() for g in groups])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("adt", ["f32", "bf16"])
+def test_iac_step2_equals_two_single_steps(adt):
+    """The two-direction launch (K1 read once) must reproduce two single-direction launches bit for bit."""
+    from fcvsr_amd import hip
+    L = hip.lib()
+    B, Cc, H, W = 2, 64, 19, 41
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16}[adt]
+    prev = [nhwc(_rand(B, Cc, H, W, seed=21 + d)).to(tdt) for d in range(2)]
+    fin = [nhwc(_rand(B, Cc, H, W, seed=31 + d)).to(tdt) for d in range(2)]
+    offs = nhwc(_rand(B, 4, H, W, seed=41) * 2.5)                  # channels (0,1): forward, (2,3): backward
+    k1 = nhwc(_rand(B, 3 * Cc, H, W, seed=51)).to(tdt)
+    kv = hip.view(k1)
+    ref = []
+    for d in range(2):
+        out = torch.empty_like(prev[d])
+        pv, ov, fv, dv = hip.view(prev[d]), hip.view(offs[..., 2 * d:2 * d + 2]), hip.view(fin[d]), hip.view(out)
+        hip.check(L.fcvsr_iac_step(C.byref(pv), C.byref(ov), C.byref(kv), C.byref(fv), 0.1, B, H, W, C.byref(dv),
+                                   hip.stream_ptr()), "iac_step")
+        ref.append(out)
+    V2 = hip.View * 2
+    outs = [torch.empty_like(prev[0]), torch.empty_like(prev[1])]
+    hip.check(L.fcvsr_iac_step2(V2(hip.view(prev[0]), hip.view(prev[1])),
+                                V2(hip.view(offs[..., 0:2]), hip.view(offs[..., 2:4])), C.byref(kv),
+                                V2(hip.view(fin[0]), hip.view(fin[1])), 0.1, B, H, W,
+                                V2(hip.view(outs[0]), hip.view(outs[1])), hip.stream_ptr()), "iac_step2")
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], ref[0]) and torch.equal(outs[1], ref[1])

@@ -195,6 +195,8 @@ class _GShiftBase(nn.Module):
         # MFMA dtype instead of f32 - half the HBM bytes and staging instructions.  Spectra, offsets, MultiFreq_Refinment
         # internals, ContextBlock statistics and all accumulation stay f32.
         self.trunk16 = os.environ.get("FCVSR_TRUNK16", "1") == "1"
+        # 16-bit modes, n_features == 64: compute the adaptive kernels (F[1]) inside the IAC kernel instead of storing them
+        self.fold_f1 = os.environ.get("FCVSR_FOLD_F1", "1") == "1"
         # capture the launch sequence of a forward in a hipGraph (per input shape) and replay it
         self.use_graph = os.environ.get("FCVSR_GRAPH", "0") == "1"
 

@@ -10,6 +10,7 @@
 // (3*C values per pixel per step), read once from HBM (second touch hits L2) in f32 or the 16-bit MFMA dtype.
 #include <stdlib.h>
 #include "common.h"
+#include "mfma_util.h"
 
 namespace fcvsr {
 
@@ -270,21 +271,32 @@ struct IacDir {
 };
 struct IacArgs {
   IacDir d[2];            // forward / backward alignment direction (ND = 1 uses d[0] only)
-  View k1;
+  View k1;                // FK = false: the 3*C adaptive-kernel channels of this iteration
+  View k0;                // FK = true: the 64-channel input of the last kernel-predictor layer (F[1], a 1x1 convolution) ...
+  const uint16_t* wk;     // ... its 192 x 64 weight rows of this iteration (MFMA dtype, cin contiguous) ...
+  const float* kbias;     // ... and their bias
   float slope;
   int B, H, W, tiles_x, tiles_y;
 };
 
+constexpr int kKtRow = 3 * kJC + 8;                   // halfwords per pixel row of the predicted-kernel tile in LDS
+
 // ND = 2: both alignment directions of one IAC iteration in one launch.  They use the SAME adaptive kernels
 // (reference :1524-1545 passes Pred_K to IAC for the forward and the backward group alike), so K1 - half of the bytes
 // a step reads - is fetched once and serves both.
-template <int KDT, int ADT, int ND>
-__global__ __launch_bounds__(256) void iac_step64_kernel(IacArgs a) {
+// FK = true: the adaptive kernels are never materialised in HBM.  The last layer of the kernel predictor is a 1x1
+// convolution (reference :1416, F[1]), so the 3*C kernel values of the tile's 4 x 18 pixels are one small GEMM
+// (192 x 64) x (64 x 72): 18 MFMA tiles spread over the 4 waves, operands straight from L2 (weights) / HBM (the 64-channel
+// predictor features), result rounded to the MFMA dtype into LDS - exactly what the stand-alone F[1] launch would have
+// stored, minus 1152 bytes written and 2 x 1152 bytes read per pixel and iteration set.
+template <int KDT, int ADT, int ND, bool FK>
+__global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
   const View k1 = a.k1;
   const float slope = a.slope;
   const int H = a.H, W = a.W, tiles_x = a.tiles_x, tiles_y = a.tiles_y;
   __shared__ __align__(16) float s_s[kIHY * kIHX * kJC];
   __shared__ __align__(16) float v_s[kIY * kIHX * kJC];
+  __shared__ __align__(16) uint16_t kt_s[FK ? kIY * kIHX * kKtRow : 8];
   const int tid = threadIdx.x;
   const int oct = tid & 7, ps = tid >> 3;              // 8-channel group, pixel slot (32 per pass)
   const int c0 = blockIdx.y * kJC + oct * 8;
@@ -300,21 +312,76 @@ __global__ __launch_bounds__(256) void iac_step64_kernel(IacArgs a) {
   // ---- loads that do not depend on the offsets: K1 and feat_in of the lane's two interior pixels, K1 of its halo column ----
   // interior pixel of pass j: p = j*32 + ps -> (y, x) = (p >> 4, p & 15); halo-column pixel (ps < 8): y = ps >> 1, hx = 0 or 17
   PackK<KDT> kin[2], khal;
-  const long long kb = (long long)b * k1.sb + c0 * 3;
+  if (!FK) {
+    const long long kb = (long long)b * k1.sb + c0 * 3;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int p = j * 32 + ps;
-    int gy = ty0 + (p >> 4), gx = tx0 + (p & 15);
-    gy = gy > H - 1 ? H - 1 : gy;
-    gx = gx > W - 1 ? W - 1 : gx;
-    kin[j] = ld_k24<KDT>(k1.p, kb + (long long)gy * k1.sy + (long long)gx * k1.sx);
+    for (int j = 0; j < 2; ++j) {
+      const int p = j * 32 + ps;
+      int gy = ty0 + (p >> 4), gx = tx0 + (p & 15);
+      gy = gy > H - 1 ? H - 1 : gy;
+      gx = gx > W - 1 ? W - 1 : gx;
+      kin[j] = ld_k24<KDT>(k1.p, kb + (long long)gy * k1.sy + (long long)gx * k1.sx);
+    }
+    {
+      int gy = ty0 + (ps >> 1), gx = tx0 + ((ps & 1) ? kIX : -1);
+      gy = gy > H - 1 ? H - 1 : gy;
+      gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
+      if (ps < 8) khal = ld_k24<KDT>(k1.p, kb + (long long)gy * k1.sy + (long long)gx * k1.sx);
+    }
   }
-  {
-    int gy = ty0 + (ps >> 1), gx = tx0 + ((ps & 1) ? kIX : -1);
-    gy = gy > H - 1 ? H - 1 : gy;
-    gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
-    if (ps < 8) khal = ld_k24<KDT>(k1.p, kb + (long long)gy * k1.sy + (long long)gx * k1.sx);
+  // ---- kernel-predictor GEMM (FK): D[cout][pixel] = W[cout][:] . k0[pixel][:] + bias, 6 cout tiles x 3 pixel tiles.
+  // Wave w owns cout tile w for all three pixel tiles; waves 0 and 1 also take cout tiles 4 and 5.  Every operand load
+  // (12 pixel fragments + 4 or 8 weight fragments) is issued here in one batch; the MFMAs run after the warp phase of the
+  // first direction has issued its own loads, so the two latencies overlap.
+  constexpr bool BF = KDT == FCVSR_BF16;
+  const int lane = tid & 63, wave = tid >> 6, mr = lane & 31, hh = lane >> 5;
+  uint4 kf[3][4], wf[2][4];
+  if (FK) {
+    const uint16_t* k0p = reinterpret_cast<const uint16_t*>(a.k0.p) + (long long)b * a.k0.sb + hh * 8;
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+      int p = nt * 32 + mr;
+      p = p < kIY * kIHX ? p : kIY * kIHX - 1;
+      const int y = p / kIHX, hx = p - y * kIHX;
+      int gy = ty0 + y, gx = tx0 + hx - 1;
+      gy = gy > H - 1 ? H - 1 : gy;
+      gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
+      const uint16_t* kp = k0p + (long long)gy * a.k0.sy + (long long)gx * a.k0.sx;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) kf[nt][kk] = *reinterpret_cast<const uint4*>(kp + kk * 16);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int mt = wave + 4 * q;                     // q = 1 exists for waves 0 and 1 only
+      const uint16_t* wp = a.wk + ((mt < 6 ? mt : wave) * 32 + mr) * kJC + hh * 8;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) wf[q][kk] = *reinterpret_cast<const uint4*>(wp + kk * 16);
+    }
   }
+  auto predictor_gemm = [&]() {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int mt = wave + 4 * q;
+      if (mt < 6) {                                    // wave-uniform
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+          f32x16_t acc;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) acc = mfma<BF>(wf[q][kk], kf[nt][kk], acc);
+          const int p = nt * 32 + mr;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int co = mt * 32 + 8 * g + 4 * hh;   // acc[4g..4g+3] = couts co..co+3 of pixel column mr
+            const float4 b4 = *reinterpret_cast<const float4*>(a.kbias + co);
+            const uint2 pk = cvt4<BF>(make_float4(acc[4 * g] + b4.x, acc[4 * g + 1] + b4.y, acc[4 * g + 2] + b4.z, acc[4 * g + 3] + b4.w));
+            if (p < kIY * kIHX) *reinterpret_cast<uint2*>(kt_s + p * kKtRow + co) = pk;
+          }
+        }
+      }
+    }
+  };
 
 #pragma unroll
   for (int dir = 0; dir < ND; ++dir) {
@@ -349,6 +416,7 @@ __global__ __launch_bounds__(256) void iac_step64_kernel(IacArgs a) {
     cgx[it] = gx;
     cgy[it] = gy;
   }
+  if (FK && dir == 0) predictor_gemm();                // operands requested above, together with the offsets
   Pack8<ADT> tap[NP][4];
   float tw[NP][4];
 #pragma unroll
@@ -393,6 +461,18 @@ __global__ __launch_bounds__(256) void iac_step64_kernel(IacArgs a) {
   }
   __syncthreads();
 
+  if (FK && dir == 0) {                                // the predicted kernels of the lane's pixels: LDS -> registers, once
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int p = j * 32 + ps;
+      const uint4* kq = reinterpret_cast<const uint4*>(kt_s + ((p >> 4) * kIHX + (p & 15) + 1) * kKtRow + oct * 24);
+      kin[j].q[0] = kq[0]; kin[j].q[1] = kq[1]; kin[j].q[2] = kq[2];
+    }
+    if (ps < 8) {
+      const uint4* kq = reinterpret_cast<const uint4*>(kt_s + ((ps >> 1) * kIHX + ((ps & 1) ? kIHX - 1 : 0)) * kKtRow + oct * 24);
+      khal.q[0] = kq[0]; khal.q[1] = kq[1]; khal.q[2] = kq[2];
+    }
+  }
   // ---- phase 2: v[y][hx] = sum_t s[y+t][hx] * K1[y][clamp(hx)][c*3+t] ---------------------------------------------------
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -459,11 +539,11 @@ static bool quad_ok(const fcvsr_view* v, int dt) {
   return v->sx % g == 0 && v->sy % g == 0 && v->sb % g == 0 && ((uintptr_t)v->ptr % al) == 0;
 }
 
-template <int KDT, int ND>
+template <int KDT, int ND, bool FK = false>
 static void launch_iac64(int adt, dim3 grid, hipStream_t st, const IacArgs& a) {
-  if (adt == FCVSR_F32) hipLaunchKernelGGL((iac_step64_kernel<KDT, FCVSR_F32, ND>), grid, dim3(256), 0, st, a);
-  else if (adt == FCVSR_BF16) hipLaunchKernelGGL((iac_step64_kernel<KDT, FCVSR_BF16, ND>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((iac_step64_kernel<KDT, FCVSR_F16, ND>), grid, dim3(256), 0, st, a);
+  if (adt == FCVSR_F32) hipLaunchKernelGGL((iac_step64_kernel<KDT, FCVSR_F32, ND, FK>), grid, dim3(256), 0, st, a);
+  else if (adt == FCVSR_BF16) hipLaunchKernelGGL((iac_step64_kernel<KDT, FCVSR_BF16, ND, FK>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((iac_step64_kernel<KDT, FCVSR_F16, ND, FK>), grid, dim3(256), 0, st, a);
 }
 
 template <int KDT>
@@ -473,7 +553,7 @@ static void launch_iac(int adt, bool wide, dim3 grid, hipStream_t st, View pv, V
     IacArgs a;
     a.d[0].prev = pv; a.d[0].off = ov; a.d[0].fin = fv; a.d[0].dst = dv;
     a.d[1] = a.d[0];
-    a.k1 = kv; a.slope = slope; a.B = B; a.H = H; a.W = W; a.tiles_x = tx; a.tiles_y = ty;
+    a.k1 = kv; a.k0 = kv; a.wk = nullptr; a.kbias = nullptr; a.slope = slope; a.B = B; a.H = H; a.W = W; a.tiles_x = tx; a.tiles_y = ty;
     launch_iac64<KDT, 1>(adt, grid, st, a);
     return;
   }
@@ -541,12 +621,49 @@ extern "C" int fcvsr_iac_step2(const fcvsr_view* prev, const fcvsr_view* off, co
   for (int d = 0; d < 2; ++d) {
     a.d[d].prev = to_view(prev[d]); a.d[d].off = to_view(off[d]); a.d[d].fin = to_view(feat_in[d]); a.d[d].dst = to_view(dst[d]);
   }
-  a.k1 = to_view(*k1); a.slope = slope; a.B = B; a.H = H; a.W = W; a.tiles_x = tx; a.tiles_y = ty;
+  a.k1 = to_view(*k1); a.k0 = a.k1; a.wk = nullptr; a.kbias = nullptr; a.slope = slope; a.B = B; a.H = H; a.W = W; a.tiles_x = tx; a.tiles_y = ty;
   hipStream_t st = (hipStream_t)stream;
   if (k1->dtype == FCVSR_F32) launch_iac64<FCVSR_F32, 2>(adt, grid, st, a);
   else if (k1->dtype == FCVSR_BF16) launch_iac64<FCVSR_BF16, 2>(adt, grid, st, a);
   else if (k1->dtype == FCVSR_F16) launch_iac64<FCVSR_F16, 2>(adt, grid, st, a);
   else FCVSR_CHECK_ARG(false, "bad k1 dtype");
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fcvsr_iac_step2_fused(const fcvsr_view* prev, const fcvsr_view* off, const fcvsr_view* k0, const void* wk,
+                                     const float* kbias, const fcvsr_view* feat_in, float slope, int B, int H, int W,
+                                     const fcvsr_view* dst, void* stream) {
+  FCVSR_CHECK_ARG(prev && off && k0 && wk && kbias && feat_in && dst && prev[0].ptr, "null argument");
+  const int adt = prev[0].dtype;
+  FCVSR_CHECK_ARG(adt == FCVSR_F32 || adt == FCVSR_BF16 || adt == FCVSR_F16, "bad feature dtype");
+  const int fa = adt == FCVSR_F32 ? 4 : 8;
+  for (int d = 0; d < 2; ++d) {
+    FCVSR_CHECK_ARG(quad_ok(&prev[d], adt) && quad_ok(&feat_in[d], adt) && quad_ok(&dst[d], adt),
+                    "prev/feat_in/dst: same dtype, channel-contiguous, aligned");
+    FCVSR_CHECK_ARG(off[d].ptr && off[d].c >= 2 && off[d].dtype == FCVSR_F32, "off needs 2 f32 channels");
+    FCVSR_CHECK_ARG(prev[d].c == kJC && dst[d].c == kJC && feat_in[d].c == kJC, "the fused predictor handles C == 64");
+    const fcvsr_view* vs[3] = {&prev[d], &feat_in[d], &dst[d]};
+    for (const fcvsr_view* v : vs)
+      FCVSR_CHECK_ARG(((uintptr_t)v->ptr % 16) == 0 && v->sx % fa == 0 && v->sy % fa == 0 && v->sb % fa == 0,
+                      "16-byte aligned feature views");
+  }
+  FCVSR_CHECK_ARG(k0->ptr && (k0->dtype == FCVSR_BF16 || k0->dtype == FCVSR_F16) && k0->sc == 1 && k0->c == kJC &&
+                      ((uintptr_t)k0->ptr % 16) == 0 && k0->sx % 8 == 0 && k0->sy % 8 == 0 && k0->sb % 8 == 0,
+                  "k0: 64 contiguous 16-bit channels, 16-byte aligned");
+  FCVSR_CHECK_ARG(((uintptr_t)wk % 16) == 0 && ((uintptr_t)kbias % 16) == 0, "weights / bias must be 16-byte aligned");
+  FCVSR_CHECK_ARG(B > 0 && H > 0 && W > 0, "bad sizes");
+  const int tx = cdiv(W, kIX), ty = cdiv(H, kIY);
+  dim3 grid(B * tx * ty, 1);
+  IacArgs a;
+  for (int d = 0; d < 2; ++d) {
+    a.d[d].prev = to_view(prev[d]); a.d[d].off = to_view(off[d]); a.d[d].fin = to_view(feat_in[d]); a.d[d].dst = to_view(dst[d]);
+  }
+  a.k1 = to_view(*k0); a.k0 = to_view(*k0); a.wk = (const uint16_t*)wk; a.kbias = kbias;
+  a.slope = slope; a.B = B; a.H = H; a.W = W; a.tiles_x = tx; a.tiles_y = ty;
+  hipStream_t st = (hipStream_t)stream;
+  if (k0->dtype == FCVSR_BF16) launch_iac64<FCVSR_BF16, 2, true>(adt, grid, st, a);
+  else launch_iac64<FCVSR_F16, 2, true>(adt, grid, st, a);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

@@ -296,10 +296,14 @@ class Engine:
         k0 = self._new(dev, B, H, W, n, dtype=self._adt())
         # the adaptive kernels feed only the IAC kernel: in the 16-bit modes they are stored in the MFMA dtype
         fused_iac = n % 32 == 0                       # fused kernel works on 32-channel slabs; else 3-kernel f32 path
-        K = self._new(dev, B, H, W, A * 3 * n, dtype=self._adt() if fused_iac else torch.float32)
         self._conv("MGAA.conv_KP", [x2], kp)
         self._conv("MGAA.F.0", [kp], k0)
-        self._conv("MGAA.F.1", [k0], K)
+        # 16-bit modes, n = 64: F[1] (a 1x1 convolution) is folded into the IAC kernel - the A*3n adaptive-kernel channels
+        # (1152 bytes per pixel) are computed per tile and never stored
+        fold_f1 = fused_iac and n == 64 and self.precision != "f32" and getattr(self._model(), "fold_f1", True)
+        if not fold_f1:
+            K = self._new(dev, B, H, W, A * 3 * n, dtype=self._adt() if fused_iac else torch.float32)
+            self._conv("MGAA.F.1", [k0], K)
 
         # iterative alignment: warp -> SAC(kernel1 twice) -> + feat_in -> LeakyReLU(0.1)
         fdt_act = x1.dtype                               # f32, or the 16-bit activation dtype (trunk16)
@@ -316,8 +320,12 @@ class Engine:
             V2 = hip.View * 2
             cur = [x1, x3]
             fins = V2(view(x1), view(x3))
+            if fold_f1:
+                wk, bk, _, _ = self._weights("MGAA.F.1", self._adt())
+                k0_v = view(k0)
             for i in range(A):
-                k_v = view(K[..., i * 3 * n:(i + 1) * 3 * n])
+                if not fold_f1:
+                    k_v = view(K[..., i * 3 * n:(i + 1) * 3 * n])
                 if i == A - 1:
                     dsts = [al[..., :n], al[..., n:]]
                 else:
@@ -325,7 +333,12 @@ class Engine:
                 prevs = V2(view(cur[0]), view(cur[1]))
                 offs = V2(view(offsets[..., 2 * i:2 * i + 2]), view(offsets[..., 2 * (A + i):2 * (A + i) + 2]))
                 dv2 = V2(view(dsts[0]), view(dsts[1]))
-                check(L.fcvsr_iac_step2(prevs, offs, C.byref(k_v), fins, 0.1, B, H, W, dv2, st), "fcvsr_iac_step2")
+                if fold_f1:
+                    check(L.fcvsr_iac_step2_fused(prevs, offs, C.byref(k0_v), wk.data_ptr() + i * 3 * n * 64 * 2,
+                                                  bk.data_ptr() + i * 3 * n * 4, fins, 0.1, B, H, W, dv2, st),
+                          "fcvsr_iac_step2_fused")
+                else:
+                    check(L.fcvsr_iac_step2(prevs, offs, C.byref(k_v), fins, 0.1, B, H, W, dv2, st), "fcvsr_iac_step2")
                 cur = dsts
         else:
             for d, fin in enumerate((x1, x3)):

@@ -138,6 +138,13 @@ int fcvsr_iac_step(const fcvsr_view* prev, const fcvsr_view* off, const fcvsr_vi
  * (forward, backward); the two directions share k1 (:1524-1545), which is then read once.  C % 64 == 0. */
 int fcvsr_iac_step2(const fcvsr_view* prev, const fcvsr_view* off, const fcvsr_view* k1, const fcvsr_view* feat_in,
                     float slope, int B, int H, int W, const fcvsr_view* dst, void* stream);
+/* fcvsr_iac_step2 with the last kernel-predictor layer (F[1], a 1x1 convolution, :1416) folded in: the 3*C adaptive
+ * kernel channels of the iteration are computed per tile on the matrix cores from k0 (the 64-channel, 16-bit input of
+ * F[1]) and never stored.  wk: this iteration's 192 x 64 weight rows in k0's dtype (cin contiguous, i.e. a row block of
+ * the MFMA packing of F[1]); kbias: their 192 f32 biases.  C == 64. */
+int fcvsr_iac_step2_fused(const fcvsr_view* prev, const fcvsr_view* off, const fcvsr_view* k0, const void* wk,
+                          const float* kbias, const fcvsr_view* feat_in, float slope, int B, int H, int W,
+                          const fcvsr_view* dst, void* stream);
 
 /* ---- MultiFreq_Refinment pieces (CVSR_freq.py:2104-2133, :2201-2254) ---------------------------------------- */
 /* DivEnh expressions, i==0 (first=1): t=f-mean_f; e1=0.2*a*t*f+b*f.  i>0: t=f-s_f+0.2*s_o; e1 as above;

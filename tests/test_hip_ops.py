@@ -345,3 +345,40 @@ def test_iac_step2_equals_two_single_steps(adt):
                                 V2(hip.view(outs[0]), hip.view(outs[1])), hip.stream_ptr()), "iac_step2")
     torch.cuda.synchronize()
     assert torch.equal(outs[0], ref[0]) and torch.equal(outs[1], ref[1])
+
+
+@pytest.mark.parametrize("adt,kdt", [("bf16", "bf16"), ("f32", "bf16"), ("f16", "f16")])
+def test_iac_step2_fused_predictor_equals_unfused(adt, kdt):
+    """F[1] folded into the IAC kernel: same result as the stand-alone 1x1 MFMA convolution (16-bit K) followed by the
+    two-direction IAC launch - the fold changes where the kernels live (LDS instead of HBM), not their values."""
+    from fcvsr_amd import hip
+    L = hip.lib()
+    B, Cc, H, W = 2, 64, 18, 37
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[adt]
+    mdt = {"bf16": torch.bfloat16, "f16": torch.float16}[kdt]
+    mcode = hip.BF16 if kdt == "bf16" else hip.F16
+    prev = [nhwc(_rand(B, Cc, H, W, seed=61 + d)).to(tdt) for d in range(2)]
+    fin = [nhwc(_rand(B, Cc, H, W, seed=71 + d)).to(tdt) for d in range(2)]
+    offs = nhwc(_rand(B, 4, H, W, seed=81) * 2.5)
+    k0 = nhwc(_rand(B, Cc, H, W, seed=91)).to(mdt)
+    w = _rand(3 * 3 * Cc, Cc, 1, 1, seed=92).cuda() / 8.0         # 3 iterations x 192 rows
+    bias = _rand(3 * 3 * Cc, seed=93).cuda() * 0.1
+    wp = hip.pack_conv_weight_mfma(w, mdt)
+    K = torch.empty(B, H, W, 3 * 3 * Cc, device="cuda", dtype=mdt)
+    hip.conv2d_mfma([dict(srcs=[k0], dst=K)], wp, 1, 3 * 3 * Cc, mcode, bias=bias)
+    V2 = hip.View * 2
+    it = 1                                                          # middle iteration: non-zero row / bias offsets
+    kv = hip.view(K[..., it * 192:(it + 1) * 192])
+    ref = [torch.empty_like(prev[0]), torch.empty_like(prev[1])]
+    args = (V2(hip.view(prev[0]), hip.view(prev[1])), V2(hip.view(offs[..., 0:2]), hip.view(offs[..., 2:4])))
+    fins = V2(hip.view(fin[0]), hip.view(fin[1]))
+    hip.check(L.fcvsr_iac_step2(args[0], args[1], C.byref(kv), fins, 0.1, B, H, W,
+                                V2(hip.view(ref[0]), hip.view(ref[1])), hip.stream_ptr()), "iac_step2")
+    out = [torch.empty_like(prev[0]), torch.empty_like(prev[1])]
+    k0v = hip.view(k0)
+    hip.check(L.fcvsr_iac_step2_fused(args[0], args[1], C.byref(k0v), wp.data_ptr() + it * 192 * 64 * 2,
+                                      bias.data_ptr() + it * 192 * 4, fins, 0.1, B, H, W,
+                                      V2(hip.view(out[0]), hip.view(out[1])), hip.stream_ptr()), "iac_step2_fused")
+    torch.cuda.synchronize()
+    for o, r_ in zip(out, ref):
+        assert torch.equal(o, r_)

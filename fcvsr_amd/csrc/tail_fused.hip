@@ -1,0 +1,186 @@
+// Fused end of the up-sampler of GShiftNet_S (reference CVSR_freq.py:2605-2607, :2642-2645):
+//     out += conv_last0( PReLU( PixelShuffle2( upconv2(u1) ) ) )          upconv2: 1x1, 64 -> 256; conv_last0: 3x3, 64 -> 1
+// The 64-channel tensor at the output resolution (B x 4H x 4W x 64: the largest activation of the whole path, 118 MB per
+// clip in 16-bit) is never written.  One workgroup produces an 8 x 32 tile of output pixels:
+//   1. GEMM 1 (v_mfma 32x32x16): the 6 x 18 pixels of u1 under the tile's 10 x 34 halo times the 256 x 64 weight block.  Wave
+//      w owns sub-pixel w (rows w*64 .. w*64+63 of the sub-pixel-major packing), so PixelShuffle is just the LDS address
+//      the result is written to; bias, PReLU, zero padding outside the image and the rounding to the MFMA dtype (what
+//      the stand-alone layer would have stored) happen on the way.
+//   2. GEMM 2 (v_mfma 16x16x32): conv_last0 as "taps are output columns": P[pixel][tap] = sum_c u2[pixel][c] * w[tap][c] for
+//      the 340 halo pixels - 44 small MFMAs instead of 576 multiply-adds per output pixel on the vector ALU.
+//   3. out[y][x] += bias + sum_tap P[y+dy][x+dx][tap]   (out holds the bilinear x4 base skip).
+// HBM traffic per output pixel: 14 bytes of u1 (with halo) + 8 bytes of out, instead of 128 written + ~170 read.
+#include "common.h"
+#include "mfma_util.h"
+
+namespace fcvsr {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int kTfTH = 8, kTfTW = 32;                       // output tile
+constexpr int kTfHH = kTfTH + 2, kTfHW = kTfTW + 2;        // halo of the 3x3 convolution (output resolution)
+constexpr int kTfNHP = kTfHH * kTfHW;                      // 340
+constexpr int kTfUH = kTfTH / 2 + 2, kTfUW = kTfTW / 2 + 2;   // 6 x 18 pixels of u1
+constexpr int kTfNU = kTfUH * kTfUW;                       // 108
+constexpr int kTfRow = 64 + 8;                             // halfwords per halo pixel in LDS (padded: conflict-free fragments)
+constexpr int kTfPRow = 9;                                 // floats per pixel of the tap table (odd stride)
+constexpr int kTfNPT = (kTfNHP + 15) / 16;                 // 22 pixel tiles of GEMM 2
+
+struct TailArgs {
+  View u1;                 // (B, H2, W2, 64), 16-bit
+  const uint16_t* w2;      // [256][64] upconv2, rows sub-pixel-major ((2i+j)*64 + c), MFMA dtype
+  const float* b2;         // [256] bias in the same row order (may be null)
+  const float* slope;      // PReLU slope (one shared scalar, :2609)
+  const uint16_t* wl;      // [16][64] conv_last0: row = tap (ky*3+kx), rows 9..15 zero
+  const float* bl;         // conv_last0 bias (1 value, may be null)
+  View out;                // (B, 2*H2, 2*W2, 1) f32, read-modify-write
+  int B, H2, W2, tiles_x, tiles_y;
+};
+
+template <bool BF16>
+__device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
+  if (BF16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs a) {
+  __shared__ __align__(16) uint16_t u2_s[kTfNHP * kTfRow];
+  __shared__ __align__(16) float p_s[kTfNPT * 16 * kTfPRow];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  int t = blockIdx.x;
+  {                                                        // contiguous runs of tiles per XCD (halo rows of u1 hit its L2)
+    const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = t & 7, loc = t >> 3;
+    t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  }
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int b = t / per_img;
+  const int t2 = t - b * per_img;
+  const int Y0 = (t2 / a.tiles_x) * kTfTH, X0 = (t2 % a.tiles_x) * kTfTW;
+  const int HH = 2 * a.H2, WW = 2 * a.W2;
+
+  // ---- GEMM 1: u2 = PReLU(W2 . u1 + b2), wave = sub-pixel -----------------------------------------------------------------
+  {
+    const int r = lane & 31, h = lane >> 5;
+    const uint16_t* ub = reinterpret_cast<const uint16_t*>(a.u1.p) + (long long)b * a.u1.sb + h * 8;
+    uint4 kf[4][4], wf[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      int p = nt * 32 + r;
+      p = p < kTfNU ? p : kTfNU - 1;
+      const int uy = p / kTfUW, ux = p - uy * kTfUW;
+      int gy = (Y0 >> 1) - 1 + uy, gx = (X0 >> 1) - 1 + ux;
+      gy = gy < 0 ? 0 : (gy > a.H2 - 1 ? a.H2 - 1 : gy);    // clamped pixels only feed halo positions outside the image,
+      gx = gx < 0 ? 0 : (gx > a.W2 - 1 ? a.W2 - 1 : gx);    // which are stored as zeros below
+      const uint16_t* up = ub + (long long)gy * a.u1.sy + (long long)gx * a.u1.sx;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) kf[nt][kk] = *reinterpret_cast<const uint4*>(up + kk * 16);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint16_t* wp = a.w2 + ((wave * 2 + q) * 32 + r) * 64 + h * 8;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) wf[q][kk] = *reinterpret_cast<const uint4*>(wp + kk * 16);
+    }
+    const float slope = a.slope[0];
+    const int sy = wave >> 1, sx = wave & 1;                // this wave's sub-pixel
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        f32x16_t acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = mfma<BF16>(wf[q][kk], kf[nt][kk], acc);
+        const int p = nt * 32 + r;
+        const int uy = p / kTfUW, ux = p - uy * kTfUW;
+        const int hr = 2 * uy + sy - 1, hc = 2 * ux + sx - 1;   // position inside the 10 x 34 halo
+        const int Y = Y0 - 1 + hr, X = X0 - 1 + hc;
+        const bool keep = p < kTfNU && hr >= 0 && hr < kTfHH && hc >= 0 && hc < kTfHW;
+        const bool inside = Y >= 0 && Y < HH && X >= 0 && X < WW;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = q * 32 + 8 * g + 4 * h;             // acc[4g..4g+3] = channels c..c+3 of sub-pixel `wave`
+          float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+          if (a.b2) {
+            const float4 b4 = *reinterpret_cast<const float4*>(a.b2 + wave * 64 + c);
+            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+          }
+          v.x = v.x >= 0.f ? v.x : v.x * slope; v.y = v.y >= 0.f ? v.y : v.y * slope;
+          v.z = v.z >= 0.f ? v.z : v.z * slope; v.w = v.w >= 0.f ? v.w : v.w * slope;
+          if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);  // zero padding of conv_last0
+          if (keep) *reinterpret_cast<uint2*>(u2_s + (hr * kTfHW + hc) * kTfRow + c) = cvt4<BF16>(v);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- GEMM 2: P[pixel][tap] = u2[pixel][:] . wl[tap][:] ---------------------------------------------------------------------
+  {
+    const int r16 = lane & 15, g4 = lane >> 4;
+    uint4 wl0 = *reinterpret_cast<const uint4*>(a.wl + r16 * 64 + g4 * 8);
+    uint4 wl1 = *reinterpret_cast<const uint4*>(a.wl + r16 * 64 + g4 * 8 + 32);
+    for (int pt = wave; pt < kTfNPT; pt += 4) {
+      int px = pt * 16 + r16;
+      px = px < kTfNHP ? px : kTfNHP - 1;
+      const uint4 a0 = *reinterpret_cast<const uint4*>(u2_s + px * kTfRow + g4 * 8);
+      const uint4 a1 = *reinterpret_cast<const uint4*>(u2_s + px * kTfRow + g4 * 8 + 32);
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      acc = mfma16<BF16>(a0, wl0, acc);
+      acc = mfma16<BF16>(a1, wl1, acc);
+      // D[row][col]: col = lane & 15 (tap), row = 4 * (lane >> 4) + i (pixel within the tile)
+      if (r16 < 9) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p_s[(pt * 16 + 4 * g4 + i) * kTfPRow + r16] = acc[i];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- out += bias + sum over the 9 taps ---------------------------------------------------------------------------------------
+  {
+    const int ty = tid >> 5, tx = tid & 31;
+    const int Y = Y0 + ty, X = X0 + tx;
+    if (Y < HH && X < WW) {
+      float s = a.bl ? a.bl[0] : 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) s += p_s[((ty + dy) * kTfHW + tx + dx) * kTfPRow + dy * 3 + dx];
+      float* op = a.out.p + (long long)b * a.out.sb + (long long)Y * a.out.sy + (long long)X * a.out.sx;
+      *op += s;
+    }
+  }
+}
+
+}  // namespace fcvsr
+
+using namespace fcvsr;
+
+extern "C" int fcvsr_tail_fused(const fcvsr_view* u1, const void* w2, const float* b2, const float* slope, const void* wl,
+                                const float* bl, int B, int H2, int W2, const fcvsr_view* out, void* stream) {
+  FCVSR_CHECK_ARG(u1 && u1->ptr && w2 && slope && wl && out && out->ptr, "null argument");
+  FCVSR_CHECK_ARG((u1->dtype == FCVSR_BF16 || u1->dtype == FCVSR_F16) && u1->c == 64 && u1->sc == 1 &&
+                      ((uintptr_t)u1->ptr % 16) == 0 && u1->sx % 8 == 0 && u1->sy % 8 == 0 && u1->sb % 8 == 0,
+                  "u1: 64 contiguous 16-bit channels, 16-byte aligned");
+  FCVSR_CHECK_ARG(out->dtype == FCVSR_F32 && out->c == 1, "out: one f32 channel");
+  FCVSR_CHECK_ARG(((uintptr_t)w2 % 16) == 0 && ((uintptr_t)wl % 16) == 0 && (b2 == nullptr || ((uintptr_t)b2 % 16) == 0),
+                  "weights / bias must be 16-byte aligned");
+  FCVSR_CHECK_ARG(B > 0 && H2 > 0 && W2 > 0, "bad sizes");
+  TailArgs a;
+  a.u1 = to_view(*u1); a.w2 = (const uint16_t*)w2; a.b2 = b2; a.slope = slope; a.wl = (const uint16_t*)wl; a.bl = bl;
+  a.out = to_view(*out); a.B = B; a.H2 = H2; a.W2 = W2;
+  a.tiles_x = cdiv(2 * W2, kTfTW);
+  a.tiles_y = cdiv(2 * H2, kTfTH);
+  dim3 grid(B * a.tiles_x * a.tiles_y);
+  hipStream_t st = (hipStream_t)stream;
+  if (u1->dtype == FCVSR_BF16) hipLaunchKernelGGL(tail_fused_kernel<true>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(tail_fused_kernel<false>, grid, dim3(256), 0, st, a);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}

@@ -127,6 +127,17 @@ class Engine:
             self._packed[key] = (pk, b, w.shape[0], w.shape[-1])
         return self._packed[key]
 
+    def _tap_weights(self, name, dt):
+        """A 3x3 layer with one output channel as a [16][cin] table in dtype dt: row = tap ky*3+kx, rows 9..15 zero (the
+        B operand of the 'taps are output columns' GEMM of the fused tail kernel)."""
+        key = (name, "taps", dt)
+        if key not in self._packed:
+            w = self._par[name + ".weight"].detach()             # (1, cin, 3, 3)
+            tab = torch.zeros(16, w.shape[1], device=w.device, dtype=torch.float32)
+            tab[:9] = w[0].permute(1, 2, 0).reshape(9, w.shape[1])
+            self._packed[key] = tab.to(dt).contiguous()
+        return self._packed[key]
+
     def _tdt(self):
         """Storage dtype of the SCNetbk trunk (x, t2, R, cross-scale terms, block outputs): f32, or - with
         model.trunk16 in the 16-bit modes - the MFMA operand dtype (halves the bytes and the staging instructions of
@@ -532,7 +543,8 @@ class Engine:
                 return self._run(x, m, ns, dev)
             # hipGraph mode: the ~650 launches of one forward are captured once per (shape, precision, streams, weights
             # version) and replayed, which removes the host launch cost (~9 us per ctypes launch) from the critical path.
-            key = (tuple(x.shape), self.precision, ns, str(dev), self._pack_epoch)
+            key = (tuple(x.shape), self.precision, ns, str(dev), self._pack_epoch,
+                   tuple(bool(getattr(m, f, True)) for f in ("trunk16", "fold_f1", "fuse_tail")))
             ent = self._graphs.get(key)
             if ent is None:
                 sx = x.clone()
@@ -623,15 +635,27 @@ class Engine:
         # up-sampler (:2641-2645)
         u1 = self._new(dev, B, 2 * H, 2 * W, n, dtype=self._adt())
         self._conv("upconv1", [fz], u1, act=ACT_PRELU, slope_t=a_t, ps=True)
-        u2 = self._new(dev, B, 4 * H, 4 * W, n, dtype=self._adt())
-        self._conv("upconv2", [u1], u2, act=ACT_PRELU, slope_t=a_t, ps=True)
         if out is None:
             out = self._new(dev, B, Cimg, 4 * H, 4 * W)           # NCHW boundary tensor
         out_v = out.permute(0, 2, 3, 1)
         centre = x[:, T // 2].permute(0, 2, 3, 1)                 # (B,H,W,Cimg) view of the centre LR frame
         cv, ov = view(centre), view(out_v)
         check(L.fcvsr_bilinear_up4(C.byref(cv), B, H, W, C.byref(ov), st), "fcvsr_bilinear_up4")
-        self._conv("conv_last0", [u2], out_v, res=[out_v])
+        fuse_tail = (self.precision != "f32" and n == 64 and Cimg == 1 and self._par["upconv2.weight"].shape[-1] == 1
+                     and getattr(m, "fuse_tail", True))
+        if fuse_tail:
+            # upconv2 (1x1) + PixelShuffle + PReLU + conv_last0 in one kernel: the 64-channel tensor at 4H x 4W is never stored
+            dt = self._adt()
+            w2, b2, _, _ = self._weights("upconv2", dt, True)
+            wl = self._tap_weights("conv_last0", dt)
+            bl = self._par.get("conv_last0.bias")
+            u1v = view(u1)
+            check(L.fcvsr_tail_fused(C.byref(u1v), w2.data_ptr(), ptr(b2), a_t.data_ptr(), wl.data_ptr(), ptr(bl), B,
+                                     2 * H, 2 * W, C.byref(ov), st), "fcvsr_tail_fused")
+        else:
+            u2 = self._new(dev, B, 4 * H, 4 * W, n, dtype=self._adt())
+            self._conv("upconv2", [u1], u2, act=ACT_PRELU, slope_t=a_t, ps=True)
+            self._conv("conv_last0", [u2], out_v, res=[out_v])
         if self.taps is not None:
             self.taps["out"] = out.clone()
         return out

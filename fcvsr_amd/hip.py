@@ -76,6 +76,7 @@ SIGNATURES = {
     "fcvsr_xscale": [_VP, _VP, _F, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP],
     "fcvsr_pixel_shuffle": [_VP, _VP, _I, _I, _I, _I, _VP],
     "fcvsr_bilinear_up4": [_PV, _I, _I, _I, _PV, _VP],
+    "fcvsr_tail_fused": [_PV, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _PV, _VP],
 }
 _RESTYPES = {"fcvsr_last_error": C.c_char_p}
 

@@ -179,6 +179,15 @@ int fcvsr_pixel_shuffle(const float* src, float* dst, int B, int H, int W, int C
 /* F.interpolate(scale_factor=4, bilinear, align_corners=False) (:2644): src view (B,H,W,c) -> dst view (B,4H,4W,c) */
 int fcvsr_bilinear_up4(const fcvsr_view* src, int B, int H, int W, const fcvsr_view* dst, void* stream);
 
+/* Fused end of the S-model up-sampler (:2605-2607, :2642-2645):
+ *   out += conv_last0( PReLU( PixelShuffle2( upconv2(u1) ) ) ),   upconv2 1x1 64->256, conv_last0 3x3 64->1.
+ * u1 (B,H2,W2,64) 16-bit; w2 [256][64] in u1's dtype, rows sub-pixel-major (row (2i+j)*64+c = original channel 4c+2i+j),
+ * b2 its 256 biases in the same order (or NULL); slope: the shared PReLU scalar; wl [16][64] in u1's dtype, row = tap
+ * ky*3+kx of conv_last0 (rows 9..15 zero); bl: its bias (or NULL); out (B,2*H2,2*W2,1) f32 is read-modify-written (it
+ * holds the bilinear base skip).  The (B,2*H2,2*W2,64) intermediate is never stored. */
+int fcvsr_tail_fused(const fcvsr_view* u1, const void* w2, const float* b2, const float* slope, const void* wl,
+                     const float* bl, int B, int H2, int W2, const fcvsr_view* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,9 +46,11 @@ __device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
 }
 
 template <bool BF16>
-__global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs a) {
+__global__ __launch_bounds__(256, 3) void tail_fused_kernel(TailArgs a) {
+  // 48 KiB: the tap table P of step 2 overwrites the u2 tile it was computed from (3 workgroups per CU)
   __shared__ __align__(16) uint16_t u2_s[kTfNHP * kTfRow];
-  __shared__ __align__(16) float p_s[kTfNPT * 16 * kTfPRow];
+  float* p_s = reinterpret_cast<float*>(u2_s);
+  static_assert(kTfNPT * 16 * kTfPRow * 4 <= kTfNHP * kTfRow * 2, "tap table must fit into the u2 tile");
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   int t = blockIdx.x;
@@ -61,6 +63,11 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs a) {
   const int t2 = t - b * per_img;
   const int Y0 = (t2 / a.tiles_x) * kTfTH, X0 = (t2 % a.tiles_x) * kTfTW;
   const int HH = 2 * a.H2, WW = 2 * a.W2;
+  // this thread's output pixel: its current value (the base skip) is requested now and consumed at the very end
+  const int oy = Y0 + (tid >> 5), ox = X0 + (tid & 31);
+  const bool olive = oy < HH && ox < WW;
+  float* op = a.out.p + (long long)b * a.out.sb + (long long)(olive ? oy : 0) * a.out.sy + (long long)(olive ? ox : 0) * a.out.sx;
+  const float base = *op;
 
   // ---- GEMM 1: u2 = PReLU(W2 . u1 + b2), wave = sub-pixel -----------------------------------------------------------------
   {
@@ -89,6 +96,10 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs a) {
     const int sy = wave >> 1, sx = wave & 1;                // this wave's sub-pixel
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
+      float4 bq[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        bq[g] = a.b2 ? *reinterpret_cast<const float4*>(a.b2 + wave * 64 + q * 32 + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         f32x16_t acc;
@@ -105,15 +116,13 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int c = q * 32 + 8 * g + 4 * h;             // acc[4g..4g+3] = channels c..c+3 of sub-pixel `wave`
-          float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-          if (a.b2) {
-            const float4 b4 = *reinterpret_cast<const float4*>(a.b2 + wave * 64 + c);
-            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-          }
-          v.x = v.x >= 0.f ? v.x : v.x * slope; v.y = v.y >= 0.f ? v.y : v.y * slope;
-          v.z = v.z >= 0.f ? v.z : v.z * slope; v.w = v.w >= 0.f ? v.w : v.w * slope;
-          if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);  // zero padding of conv_last0
-          if (keep) *reinterpret_cast<uint2*>(u2_s + (hr * kTfHW + hc) * kTfRow + c) = cvt4<BF16>(v);
+          float4 v = make_float4(acc[4 * g] + bq[g].x, acc[4 * g + 1] + bq[g].y, acc[4 * g + 2] + bq[g].z, acc[4 * g + 3] + bq[g].w);
+          // PReLU as max(x,0) + slope*min(x,0): the same values as the select form, in packed-f32 instructions
+          v.x = fmaf(slope, fminf(v.x, 0.f), fmaxf(v.x, 0.f)); v.y = fmaf(slope, fminf(v.y, 0.f), fmaxf(v.y, 0.f));
+          v.z = fmaf(slope, fminf(v.z, 0.f), fmaxf(v.z, 0.f)); v.w = fmaf(slope, fminf(v.w, 0.f), fmaxf(v.w, 0.f));
+          uint2 pk = cvt4<BF16>(v);
+          if (!inside) pk = make_uint2(0u, 0u);              // zero padding of conv_last0
+          if (keep) *reinterpret_cast<uint2*>(u2_s + (hr * kTfHW + hc) * kTfRow + c) = pk;
         }
       }
     }
@@ -125,18 +134,26 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs a) {
     const int r16 = lane & 15, g4 = lane >> 4;
     uint4 wl0 = *reinterpret_cast<const uint4*>(a.wl + r16 * 64 + g4 * 8);
     uint4 wl1 = *reinterpret_cast<const uint4*>(a.wl + r16 * 64 + g4 * 8 + 32);
-    for (int pt = wave; pt < kTfNPT; pt += 4) {
+    f32x4_t pacc[(kTfNPT + 3) / 4];
+#pragma unroll
+    for (int j = 0; j < (kTfNPT + 3) / 4; ++j) {
+      const int pt = wave + 4 * j;
       int px = pt * 16 + r16;
       px = px < kTfNHP ? px : kTfNHP - 1;
       const uint4 a0 = *reinterpret_cast<const uint4*>(u2_s + px * kTfRow + g4 * 8);
       const uint4 a1 = *reinterpret_cast<const uint4*>(u2_s + px * kTfRow + g4 * 8 + 32);
       f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
       acc = mfma16<BF16>(a0, wl0, acc);
-      acc = mfma16<BF16>(a1, wl1, acc);
-      // D[row][col]: col = lane & 15 (tap), row = 4 * (lane >> 4) + i (pixel within the tile)
-      if (r16 < 9) {
+      pacc[j] = mfma16<BF16>(a1, wl1, acc);
+    }
+    __syncthreads();                                       // every wave has read its u2 pixels: the tile may be overwritten
+    // D[row][col]: col = lane & 15 (tap), row = 4 * (lane >> 4) + i (pixel within the 16-pixel tile)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) p_s[(pt * 16 + 4 * g4 + i) * kTfPRow + r16] = acc[i];
+    for (int j = 0; j < (kTfNPT + 3) / 4; ++j) {
+      const int pt = wave + 4 * j;
+      if (pt < kTfNPT && r16 < 9) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p_s[(pt * 16 + 4 * g4 + i) * kTfPRow + r16] = pacc[j][i];
       }
     }
   }
@@ -145,15 +162,13 @@ __global__ __launch_bounds__(256, 2) void tail_fused_kernel(TailArgs a) {
   // ---- out += bias + sum over the 9 taps ---------------------------------------------------------------------------------------
   {
     const int ty = tid >> 5, tx = tid & 31;
-    const int Y = Y0 + ty, X = X0 + tx;
-    if (Y < HH && X < WW) {
-      float s = a.bl ? a.bl[0] : 0.f;
+    if (olive) {
+      float s = base + (a.bl ? a.bl[0] : 0.f);
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) s += p_s[((ty + dy) * kTfHW + tx + dx) * kTfPRow + dy * 3 + dx];
-      float* op = a.out.p + (long long)b * a.out.sb + (long long)Y * a.out.sy + (long long)X * a.out.sx;
-      *op += s;
+      *op = s;
     }
   }
 }

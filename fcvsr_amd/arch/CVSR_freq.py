@@ -199,6 +199,8 @@ class _GShiftBase(nn.Module):
         self.fold_f1 = os.environ.get("FCVSR_FOLD_F1", "1") == "1"
         # 16-bit modes, S model (1x1 up-convs), one image channel: upconv2 + PixelShuffle + PReLU + conv_last0 in one kernel
         self.fuse_tail = os.environ.get("FCVSR_FUSE_TAIL", "1") == "1"
+        # 16-bit modes: BlockRCB's down path as conv1x1(avgpool2(R)) (they commute) and level-grouped elementwise launches
+        self.pool_first = os.environ.get("FCVSR_POOL_FIRST", "1") == "1"
         # capture the launch sequence of a forward in a hipGraph (per input shape) and replay it
         self.use_graph = os.environ.get("FCVSR_GRAPH", "0") == "1"
 

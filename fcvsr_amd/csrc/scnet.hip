@@ -221,6 +221,201 @@ __global__ void xscale_kernel(const void* x, const void* r, float rs, const void
   st4<DT>(out, t, acc);
 }
 
+
+// ---- level-grouped variants: up to 3 pyramid levels per launch ----------------------------------------------------------
+struct GcFinishLv { const float* part; float* add; int nparts; };
+struct GcFinishArgs { GcFinishLv lv[3]; };
+
+__global__ void gc_stage2_levels_kernel(GcFinishArgs a, int C, const float* w1, const float* w2) {
+  // same arithmetic as gc_stage2_kernel; blockIdx.y selects the level
+  const GcFinishLv L = a.lv[blockIdx.y];
+  extern __shared__ float sm[];  // ctx[C], hid[C], scale[nparts]
+  float* ctx = sm;
+  float* hid = sm + C;
+  float* scale = sm + 2 * C;
+  __shared__ float red[256];
+  const int b = blockIdx.x, nblk = L.nparts;
+  const float* pb = L.part + (long long)b * nblk * (C + 2);
+  float gm = -INFINITY;
+  for (int k = threadIdx.x; k < nblk; k += blockDim.x) gm = fmaxf(gm, pb[(long long)k * (C + 2) + C]);
+  red[threadIdx.x] = gm;
+  __syncthreads();
+  for (int st = blockDim.x / 2; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+    __syncthreads();
+  }
+  const float gmax_s = red[0];
+  __syncthreads();
+  float den = 0.f;
+  for (int k = threadIdx.x; k < nblk; k += blockDim.x) {
+    const float sc = expf(pb[(long long)k * (C + 2) + C] - gmax_s);
+    scale[k] = sc;
+    den = fmaf(pb[(long long)k * (C + 2) + C + 1], sc, den);
+  }
+  red[threadIdx.x] = den;
+  __syncthreads();
+  for (int st = blockDim.x / 2; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  const float denom_s = red[0];
+  __syncthreads();
+  {
+    const int R = blockDim.x / C;
+    const int sub = threadIdx.x / C, c = threadIdx.x % C;
+    float s = 0.f;
+    if (sub < R)
+      for (int k = sub; k < nblk; k += R) s = fmaf(pb[(long long)k * (C + 2) + c], scale[k], s);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < C) {
+      float t = 0.f;
+      for (int q = 0; q < R; ++q) t += red[q * C + threadIdx.x];
+      ctx[threadIdx.x] = t / denom_s;
+    }
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < C; o += blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s = fmaf(w1[o * C + c], ctx[c], s);
+    hid[o] = s >= 0.f ? s : 0.2f * s;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < C; o += blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s = fmaf(w2[o * C + c], hid[c], s);
+    L.add[(long long)b * C + o] = s;
+  }
+}
+
+struct GcApplyLv {
+  const float4* r;
+  const float* add;
+  const void* z;
+  void* out;
+  void* pool;
+  int B, H, W;
+  int blk_begin;           // first workgroup of this level
+};
+struct GcApplyArgs { GcApplyLv lv[3]; int n; };
+
+template <int DT>
+__device__ __forceinline__ float4 gc_apply_one(const float4* r, const float* a, const void* z, void* out, long long q, float slope) {
+  const float4 rr = r[q], zz = ld4<DT>(z, q);
+  float4 v = make_float4(rr.x + a[0], rr.y + a[1], rr.z + a[2], rr.w + a[3]);
+  v.x = v.x >= 0.f ? v.x : v.x * slope; v.y = v.y >= 0.f ? v.y : v.y * slope;
+  v.z = v.z >= 0.f ? v.z : v.z * slope; v.w = v.w >= 0.f ? v.w : v.w * slope;
+  v = make_float4(v.x + zz.x, v.y + zz.y, v.z + zz.z, v.w + zz.w);
+  st4<DT>(out, q, v);
+  return v;
+}
+
+// value as it is stored (rounded to the io dtype): the pooled tensor averages what a reader of `out` would see
+template <int DT>
+__device__ __forceinline__ float4 as_stored(float4 v) {
+  if (DT == FCVSR_F32) return v;
+  if (DT == FCVSR_BF16) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 b4;
+    const b4 c = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    return make_float4((float)c[0], (float)c[1], (float)c[2], (float)c[3]);
+  }
+  typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+  const h4 c = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+  return make_float4((float)c[0], (float)c[1], (float)c[2], (float)c[3]);
+}
+
+template <int DT>
+__global__ void gc_apply_levels_kernel(GcApplyArgs a, float slope, int Cq) {
+  int li = 0;
+  if (a.n > 1 && (int)blockIdx.x >= a.lv[1].blk_begin) li = 1;
+  if (a.n > 2 && (int)blockIdx.x >= a.lv[2].blk_begin) li = 2;
+  const GcApplyLv L = a.lv[li];
+  const long long t = (long long)(blockIdx.x - L.blk_begin) * blockDim.x + threadIdx.x;
+  if (L.pool) {
+    // thread = (2x2 pixel block, channel quad): four outputs and their average
+    const int H2 = L.H >> 1, W2 = L.W >> 1;
+    const long long total = (long long)L.B * H2 * W2 * Cq;
+    if (t >= total) return;
+    const int cq = (int)(t % Cq);
+    const long long pg = t / Cq;
+    const int x2 = (int)(pg % W2), y2 = (int)((pg / W2) % H2), b = (int)(pg / ((long long)W2 * H2));
+    const float* ad = L.add + (long long)b * Cq * 4 + cq * 4;
+    const long long q00 = (((long long)b * L.H + 2 * y2) * L.W + 2 * x2) * Cq + cq;
+    const float4 v00 = as_stored<DT>(gc_apply_one<DT>(L.r, ad, L.z, L.out, q00, slope));
+    const float4 v01 = as_stored<DT>(gc_apply_one<DT>(L.r, ad, L.z, L.out, q00 + Cq, slope));
+    const float4 v10 = as_stored<DT>(gc_apply_one<DT>(L.r, ad, L.z, L.out, q00 + (long long)L.W * Cq, slope));
+    const float4 v11 = as_stored<DT>(gc_apply_one<DT>(L.r, ad, L.z, L.out, q00 + (long long)L.W * Cq + Cq, slope));
+    // torch upsample_bilinear2d order: lerp along x inside each row, then along y (weights 0.5)
+    const float4 top = make_float4(0.5f * v00.x + 0.5f * v01.x, 0.5f * v00.y + 0.5f * v01.y, 0.5f * v00.z + 0.5f * v01.z, 0.5f * v00.w + 0.5f * v01.w);
+    const float4 bot = make_float4(0.5f * v10.x + 0.5f * v11.x, 0.5f * v10.y + 0.5f * v11.y, 0.5f * v10.z + 0.5f * v11.z, 0.5f * v10.w + 0.5f * v11.w);
+    st4<DT>(L.pool, t, make_float4(0.5f * top.x + 0.5f * bot.x, 0.5f * top.y + 0.5f * bot.y, 0.5f * top.z + 0.5f * bot.z, 0.5f * top.w + 0.5f * bot.w));
+  } else {
+    const long long HWCq = (long long)L.H * L.W * Cq;
+    if (t >= HWCq * L.B) return;
+    const int b = (int)(t / HWCq), cq = (int)(t % Cq);
+    gc_apply_one<DT>(L.r, L.add + (long long)b * Cq * 4 + cq * 4, L.z, L.out, t, slope);
+  }
+}
+
+struct XsLv {
+  const void* x; const void* r; const void* dn; const void* up; void* out;
+  float rs;
+  int dn_pooled, B, H, W, blk_begin;
+};
+struct XsArgs { XsLv lv[3]; int n; };
+
+template <int DT>
+__global__ void xscale_levels_kernel(XsArgs a, int Cq) {
+  int li = 0;
+  if (a.n > 1 && (int)blockIdx.x >= a.lv[1].blk_begin) li = 1;
+  if (a.n > 2 && (int)blockIdx.x >= a.lv[2].blk_begin) li = 2;
+  const XsLv L = a.lv[li];
+  const int H = L.H, W = L.W;
+  const long long total = (long long)L.B * H * W * Cq;
+  const long long t = (long long)(blockIdx.x - L.blk_begin) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int cq = (int)(t % Cq);
+  const long long pg = t / Cq;
+  const int xx = (int)(pg % W);
+  const int yy = (int)((pg / W) % H);
+  const int b = (int)(pg / ((long long)W * H));
+  float4 acc = f4_axpy(L.rs, ld4<DT>(L.r, t), ld4<DT>(L.x, t));
+  if (L.dn) {
+    if (L.dn_pooled) {
+      const float4 d = ld4<DT>(L.dn, t);
+      acc = make_float4(acc.x + d.x, acc.y + d.y, acc.z + d.z, acc.w + d.w);
+    } else {
+      const int H2 = 2 * H, W2 = 2 * W;
+      const long long d0 = ((long long)b * H2 * W2) * Cq + cq;
+      const float4 a00 = ld4<DT>(L.dn, d0 + ((long long)(2 * yy) * W2 + 2 * xx) * Cq);
+      const float4 a01 = ld4<DT>(L.dn, d0 + ((long long)(2 * yy) * W2 + 2 * xx + 1) * Cq);
+      const float4 a10 = ld4<DT>(L.dn, d0 + ((long long)(2 * yy + 1) * W2 + 2 * xx) * Cq);
+      const float4 a11 = ld4<DT>(L.dn, d0 + ((long long)(2 * yy + 1) * W2 + 2 * xx + 1) * Cq);
+      const float4 top = make_float4(0.5f * a00.x + 0.5f * a01.x, 0.5f * a00.y + 0.5f * a01.y, 0.5f * a00.z + 0.5f * a01.z, 0.5f * a00.w + 0.5f * a01.w);
+      const float4 bot = make_float4(0.5f * a10.x + 0.5f * a11.x, 0.5f * a10.y + 0.5f * a11.y, 0.5f * a10.z + 0.5f * a11.z, 0.5f * a10.w + 0.5f * a11.w);
+      acc = f4_axpy(0.5f, top, acc);
+      acc = f4_axpy(0.5f, bot, acc);
+    }
+  }
+  if (L.up) {
+    const int Hh = H / 2, Wh = W / 2;
+    float sy = 0.5f * ((float)yy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+    float sx = 0.5f * ((float)xx + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < Hh - 1 ? 1 : 0), x1 = x0 + (x0 < Wh - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const long long u0 = ((long long)b * Hh * Wh) * Cq + cq;
+    const float4 u00 = ld4<DT>(L.up, u0 + ((long long)y0 * Wh + x0) * Cq), u01 = ld4<DT>(L.up, u0 + ((long long)y0 * Wh + x1) * Cq);
+    const float4 u10 = ld4<DT>(L.up, u0 + ((long long)y1 * Wh + x0) * Cq), u11 = ld4<DT>(L.up, u0 + ((long long)y1 * Wh + x1) * Cq);
+    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+    acc = f4_axpy(w00, u00, acc);
+    acc = f4_axpy(w01, u01, acc);
+    acc = f4_axpy(w10, u10, acc);
+    acc = f4_axpy(w11, u11, acc);
+  }
+  st4<DT>(L.out, t, acc);
+}
+
 }  // namespace fcvsr
 
 using namespace fcvsr;
@@ -295,6 +490,79 @@ extern "C" int fcvsr_xscale(const void* x, const void* r, float r_scale, const v
   else
     hipLaunchKernelGGL((xscale_kernel<FCVSR_F16>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, r, r_scale, dn,
                        up, out, B, H, W, C / 4);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fcvsr_gc_finish_levels(const fcvsr_gc_finish_level* lv, int n_levels, const float* w1, const float* w2, int B,
+                                      int C, void* stream) {
+  FCVSR_CHECK_ARG(lv && w1 && w2 && n_levels >= 1 && n_levels <= 3, "1..3 levels");
+  FCVSR_CHECK_ARG(B > 0 && C >= 4 && C <= 256, "bad sizes");
+  GcFinishArgs a;
+  int maxp = 0;
+  for (int l = 0; l < 3; ++l) {
+    const fcvsr_gc_finish_level& s = lv[l < n_levels ? l : 0];
+    FCVSR_CHECK_ARG(s.partial && s.add && s.nparts > 0, "null level");
+    a.lv[l].part = s.partial; a.lv[l].add = s.add; a.lv[l].nparts = s.nparts;
+    maxp = s.nparts > maxp ? s.nparts : maxp;
+  }
+  FCVSR_CHECK_ARG((2ll * C + maxp) * 4 <= 60 * 1024, "too many partials for stage-2 LDS");
+  hipLaunchKernelGGL(gc_stage2_levels_kernel, dim3(B, n_levels), dim3(256), (2 * C + maxp) * sizeof(float), (hipStream_t)stream,
+                     a, C, w1, w2);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fcvsr_gc_apply_levels(const fcvsr_gc_apply_level* lv, int n_levels, int io_dtype, float slope, int C,
+                                     void* stream) {
+  FCVSR_CHECK_ARG(lv && n_levels >= 1 && n_levels <= 3, "1..3 levels");
+  FCVSR_CHECK_ARG(C > 0 && C % 4 == 0, "C%4==0 required");
+  FCVSR_CHECK_ARG(io_dtype == FCVSR_F32 || io_dtype == FCVSR_BF16 || io_dtype == FCVSR_F16, "bad io_dtype");
+  GcApplyArgs a;
+  a.n = n_levels;
+  int blocks = 0;
+  for (int l = 0; l < 3; ++l) {
+    const fcvsr_gc_apply_level& s = lv[l < n_levels ? l : 0];
+    FCVSR_CHECK_ARG(s.r && s.add && s.z && s.out && s.B > 0 && s.H > 0 && s.W > 0, "null level");
+    FCVSR_CHECK_ARG(al16(s.r) && al16(s.z) && al16(s.out) && al16(s.pool), "16-byte alignment");
+    FCVSR_CHECK_ARG(!s.pool || (s.H % 2 == 0 && s.W % 2 == 0), "pooled output needs even H, W");
+    GcApplyLv& d = a.lv[l];
+    d.r = (const float4*)s.r; d.add = s.add; d.z = s.z; d.out = s.out; d.pool = s.pool; d.B = s.B; d.H = s.H; d.W = s.W;
+    d.blk_begin = blocks;
+    if (l < n_levels) {
+      const long long items = s.pool ? (long long)s.B * (s.H / 2) * (s.W / 2) * (C / 4) : (long long)s.B * s.H * s.W * (C / 4);
+      blocks += cdiv(items, 256);
+    }
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (io_dtype == FCVSR_F32) hipLaunchKernelGGL((gc_apply_levels_kernel<FCVSR_F32>), dim3(blocks), dim3(256), 0, st, a, slope, C / 4);
+  else if (io_dtype == FCVSR_BF16) hipLaunchKernelGGL((gc_apply_levels_kernel<FCVSR_BF16>), dim3(blocks), dim3(256), 0, st, a, slope, C / 4);
+  else hipLaunchKernelGGL((gc_apply_levels_kernel<FCVSR_F16>), dim3(blocks), dim3(256), 0, st, a, slope, C / 4);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fcvsr_xscale_levels(const fcvsr_xscale_level* lv, int n_levels, int io_dtype, int C, void* stream) {
+  FCVSR_CHECK_ARG(lv && n_levels >= 1 && n_levels <= 3, "1..3 levels");
+  FCVSR_CHECK_ARG(C > 0 && C % 4 == 0, "C%4==0 required");
+  FCVSR_CHECK_ARG(io_dtype == FCVSR_F32 || io_dtype == FCVSR_BF16 || io_dtype == FCVSR_F16, "bad io_dtype");
+  XsArgs a;
+  a.n = n_levels;
+  int blocks = 0;
+  for (int l = 0; l < 3; ++l) {
+    const fcvsr_xscale_level& s = lv[l < n_levels ? l : 0];
+    FCVSR_CHECK_ARG(s.x && s.r && s.out && s.B > 0 && s.H > 0 && s.W > 0, "null level");
+    FCVSR_CHECK_ARG(!s.up || (s.H % 2 == 0 && s.W % 2 == 0), "up source needs even H,W");
+    FCVSR_CHECK_ARG(al16(s.x) && al16(s.r) && al16(s.out) && al16(s.dn) && al16(s.up), "16-byte alignment");
+    XsLv& d = a.lv[l];
+    d.x = s.x; d.r = s.r; d.dn = s.dn; d.up = s.up; d.out = s.out; d.rs = s.r_scale; d.dn_pooled = s.dn_pooled;
+    d.B = s.B; d.H = s.H; d.W = s.W; d.blk_begin = blocks;
+    if (l < n_levels) blocks += cdiv((long long)s.B * s.H * s.W * (C / 4), 256);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (io_dtype == FCVSR_F32) hipLaunchKernelGGL((xscale_levels_kernel<FCVSR_F32>), dim3(blocks), dim3(256), 0, st, a, C / 4);
+  else if (io_dtype == FCVSR_BF16) hipLaunchKernelGGL((xscale_levels_kernel<FCVSR_BF16>), dim3(blocks), dim3(256), 0, st, a, C / 4);
+  else hipLaunchKernelGGL((xscale_levels_kernel<FCVSR_F16>), dim3(blocks), dim3(256), 0, st, a, C / 4);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

@@ -462,6 +462,8 @@ class Engine:
         parts = [self._new(x.device, x.shape[0], npt, n + 2) for x, npt in zip(xs, nparts)]
         fused_gc = self._convg(pre + ".RCB.body.2", [dict(srcs=[a], dst=t, gc_partial=pt) for a, t, pt in zip(r1, rr, parts)],
                                gc_wmask=wmask if self.precision != "f32" else None)
+        if fused_gc and getattr(m, "pool_first", True):
+            return self._block_rcb_tail_levels(pre, xs, t2, rr, parts, nparts, w1g, w2g, tdt)
         R = []
         for l, x in enumerate(xs):
             dev = x.device
@@ -494,6 +496,46 @@ class Engine:
             check(L.fcvsr_xscale(x.data_ptr(), R[l].data_ptr(), rs, ptr(d), ptr(u), y.data_ptr(), self._code(tdt), B, H, W,
                                  n, st), "fcvsr_xscale")
             outs.append(y)
+        return outs
+
+    def _block_rcb_tail_levels(self, pre, xs, t2, rr, parts, nparts, w1g, w2g, tdt):
+        """Second half of BlockRCB (:722-725, :766-777) with one launch per step for all three pyramid levels, and the
+        down path evaluated as conv1x1(avgpool2(R)) instead of avgpool2(conv1x1(R)): the two commute (both are linear, the
+        averaging weights sum to one so the bias passes through) and the convolution then runs on a quarter of the pixels."""
+        m = self._model()
+        n = m.n_feats
+        L = lib()
+        st = stream_ptr()
+        dev = xs[0].device
+        B = xs[0].shape[0]
+        code = self._code(tdt)
+        adds = [self._new(dev, B, n) for _ in xs]
+        fl = (hip.GcFinishLevel * 3)()
+        for l in range(3):
+            fl[l].partial, fl[l].add, fl[l].nparts = parts[l].data_ptr(), adds[l].data_ptr(), nparts[l]
+        check(L.fcvsr_gc_finish_levels(fl, 3, w1g.data_ptr(), w2g.data_ptr(), B, n, st), "fcvsr_gc_finish_levels")
+        R = [torch.empty_like(t) for t in t2]
+        P = [self._new(dev, B, xs[l].shape[1] // 2, xs[l].shape[2] // 2, n, dtype=tdt) for l in (0, 1)]
+        al = (hip.GcApplyLevel * 3)()
+        for l in range(3):
+            al[l].r, al[l].add, al[l].z, al[l].out = rr[l].data_ptr(), adds[l].data_ptr(), t2[l].data_ptr(), R[l].data_ptr()
+            al[l].pool = P[l].data_ptr() if l < 2 else None
+            al[l].B, al[l].H, al[l].W = B, xs[l].shape[1], xs[l].shape[2]
+        check(L.fcvsr_gc_apply_levels(al, 3, code, 0.2, n, st), "fcvsr_gc_apply_levels")
+        dn = [torch.empty_like(P[l]) for l in (0, 1)]           # dn[l] lives at level l+1's resolution
+        up = [torch.empty_like(R[l]) for l in (1, 2)]
+        self._convg(pre + ".down.0", [dict(srcs=[P[l]], dst=dn[l]) for l in (0, 1)])
+        self._convg(pre + ".up.0", [dict(srcs=[R[l]], dst=up[l - 1]) for l in (1, 2)])
+        outs = [torch.empty_like(x) for x in xs]
+        xl = (hip.XscaleLevel * 3)()
+        for l in range(3):
+            xl[l].x, xl[l].r, xl[l].out = xs[l].data_ptr(), R[l].data_ptr(), outs[l].data_ptr()
+            xl[l].dn = dn[l - 1].data_ptr() if l >= 1 else None
+            xl[l].up = up[l].data_ptr() if l <= 1 else None
+            xl[l].r_scale = 2.0 if l in (0, 2) else 1.0
+            xl[l].dn_pooled = 1
+            xl[l].B, xl[l].H, xl[l].W = B, xs[l].shape[1], xs[l].shape[2]
+        check(L.fcvsr_xscale_levels(xl, 3, code, n, st), "fcvsr_xscale_levels")
         return outs
 
     def _scnet(self, xs):
@@ -544,7 +586,7 @@ class Engine:
             # hipGraph mode: the ~650 launches of one forward are captured once per (shape, precision, streams, weights
             # version) and replayed, which removes the host launch cost (~9 us per ctypes launch) from the critical path.
             key = (tuple(x.shape), self.precision, ns, str(dev), self._pack_epoch,
-                   tuple(bool(getattr(m, f, True)) for f in ("trunk16", "fold_f1", "fuse_tail")))
+                   tuple(bool(getattr(m, f, True)) for f in ("trunk16", "fold_f1", "fuse_tail", "pool_first")))
             ent = self._graphs.get(key)
             if ent is None:
                 sx = x.clone()

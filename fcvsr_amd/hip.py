@@ -25,6 +25,20 @@ class View(C.Structure):
                 ("c", C.c_int32), ("dtype", C.c_int32)]
 
 
+class GcFinishLevel(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("add", C.c_void_p), ("nparts", C.c_int32)]
+
+
+class GcApplyLevel(C.Structure):
+    _fields_ = [("r", C.c_void_p), ("add", C.c_void_p), ("z", C.c_void_p), ("out", C.c_void_p), ("pool", C.c_void_p),
+                ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32)]
+
+
+class XscaleLevel(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("r", C.c_void_p), ("dn", C.c_void_p), ("up", C.c_void_p), ("out", C.c_void_p),
+                ("r_scale", C.c_float), ("dn_pooled", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("n_src", C.c_int32), ("src", View * 3), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
@@ -74,6 +88,9 @@ SIGNATURES = {
     "fcvsr_gc_finish": [_VP, _I, _VP, _VP, _I, _I, _VP, _VP],
     "fcvsr_gc_apply": [_VP, _VP, _VP, _VP, _I, _F, _I, _I, _I, _I, _VP],
     "fcvsr_xscale": [_VP, _VP, _F, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP],
+    "fcvsr_gc_finish_levels": [C.POINTER(GcFinishLevel), _I, _VP, _VP, _I, _I, _VP],
+    "fcvsr_gc_apply_levels": [C.POINTER(GcApplyLevel), _I, _I, _F, _I, _VP],
+    "fcvsr_xscale_levels": [C.POINTER(XscaleLevel), _I, _I, _I, _VP],
     "fcvsr_pixel_shuffle": [_VP, _VP, _I, _I, _I, _I, _VP],
     "fcvsr_bilinear_up4": [_PV, _I, _I, _I, _PV, _VP],
     "fcvsr_tail_fused": [_PV, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _PV, _VP],

@@ -173,6 +173,38 @@ int fcvsr_gc_apply(const float* r, const float* add, const void* z, void* out, i
 int fcvsr_xscale(const void* x, const void* r, float r_scale, const void* dn, const void* up, void* out, int io_dtype,
                  int B, int H, int W, int C, void* stream);
 
+/* The three calls above for all pyramid levels of a BlockRCB in ONE launch each (the small levels are launch-latency bound).
+ * fcvsr_gc_apply_levels can also emit pool = avgpool2(out) (the bilinear x0.5 of Interpolate, :623-632): the cross-scale
+ * 1x1 convolution commutes with that average, so the caller convolves the pooled tensor (a quarter of the pixels) and
+ * fcvsr_xscale_levels adds the result as dn at the level's own resolution (dn_pooled = 1). */
+typedef struct {
+  const float* partial;   /* [B][nparts][C+2] */
+  float*       add;       /* [B][C] */
+  int32_t      nparts;
+} fcvsr_gc_finish_level;
+int fcvsr_gc_finish_levels(const fcvsr_gc_finish_level* lv, int n_levels, const float* w1, const float* w2, int B, int C,
+                           void* stream);
+typedef struct {
+  const float* r;         /* (B,H,W,C) f32 */
+  const float* add;       /* [B][C] */
+  const void*  z;         /* (B,H,W,C) io_dtype */
+  void*        out;       /* (B,H,W,C) io_dtype */
+  void*        pool;      /* (B,H/2,W/2,C) io_dtype or NULL (needs even H, W) */
+  int32_t      B, H, W;
+} fcvsr_gc_apply_level;
+int fcvsr_gc_apply_levels(const fcvsr_gc_apply_level* lv, int n_levels, int io_dtype, float slope, int C, void* stream);
+typedef struct {
+  const void* x;          /* (B,H,W,C) */
+  const void* r;
+  const void* dn;         /* NULL, or (B,H,W,C) when dn_pooled, else (B,2H,2W,C) */
+  const void* up;         /* NULL or (B,H/2,W/2,C) */
+  void*       out;
+  float       r_scale;
+  int32_t     dn_pooled;
+  int32_t     B, H, W;
+} fcvsr_xscale_level;
+int fcvsr_xscale_levels(const fcvsr_xscale_level* lv, int n_levels, int io_dtype, int C, void* stream);
+
 /* ---- tail ------------------------------------------------------------------------------------------------------ */
 /* nn.PixelShuffle(2) of a dense NHWC tensor (B,H,W,C) -> (B,2H,2W,C/4) (:2634-2635) */
 int fcvsr_pixel_shuffle(const float* src, float* dst, int B, int H, int W, int C, void* stream);

@@ -245,12 +245,15 @@ class Engine:
         fdt = self._adt(freq=True)
         # the offset spectra feed only convcorr.0: stored in its operand dtype (bit-identical results, half the bytes)
         off = self._new(dev, 2 * B, H, Wf, 2 * n, dtype=fdt)
-        t0 = self._new(dev, B, H, Wf, 2 * n, dtype=fdt)
-        t1 = self._new(dev, B, H, Wf, 2 * n, dtype=fdt)
-        for d, xa in enumerate((x1f, x3f)):
-            self._conv("MGAA.convfuse.0", [xa, x2f], t0, act=ACT_RELU, freq=True)
-            self._conv("MGAA.convfuse.2", [t0], t1, act=ACT_RELU, freq=True)
-            self._conv("MGAA.convfuse.4", [t1], off[d * B:(d + 1) * B], res=[xa, x2f], res_scale=[1.0, -1.0], freq=True)
+        # both directions per launch: two problem groups sharing the weights (forward: x1f vs x2f, backward: x3f vs x2f)
+        t0 = self._new(dev, 2 * B, H, Wf, 2 * n, dtype=fdt)
+        t1 = self._new(dev, 2 * B, H, Wf, 2 * n, dtype=fdt)
+        dirs = list(enumerate((x1f, x3f)))
+        self._convg("MGAA.convfuse.0", [dict(srcs=[xa, x2f], dst=t0[d * B:(d + 1) * B]) for d, xa in dirs], act=ACT_RELU,
+                    freq=True)
+        self._convg("MGAA.convfuse.2", [dict(srcs=[t0], dst=t1)], act=ACT_RELU, freq=True)
+        self._convg("MGAA.convfuse.4", [dict(srcs=[t1[d * B:(d + 1) * B]], dst=off[d * B:(d + 1) * B], res=[xa, x2f])
+                                        for d, xa in dirs], res_scale=[1.0, -1.0], freq=True)
         s0 = self._new(dev, B, H, Wf, n, dtype=fdt)
         sim = self._new(dev, B, H, Wf, 4)
         self._conv("MGAA.convcrt.0", [x2f], s0, act=ACT_RELU, freq=True)

@@ -232,7 +232,13 @@ def conv2d_mfma(groups, wpacked: torch.Tensor, ksize: int, cout: int, mma_dtype:
         check(lib().fcvsr_conv2d_mfma(descs, n, mma_dtype, stream_ptr()), "fcvsr_conv2d_mfma")
         e1.record()
         nbytes = sum(t.numel() * t.element_size() for g in groups for t in list(g["srcs"]) + list(g.get("res", ())) + [g["dst"]])
-        PROFILE.append((e0, e1, flops, "mfma", name, nbytes))
+        # which kernel the dispatcher picks for the layers that dominate the run (see fcvsr_conv2d_mfma): the lean 3x3
+        # kernel with 16-bit source and destination = conv3_lean_kernel<BF16, 64, true, true>
+        g0 = groups[0]
+        lean16 = (ksize == 3 and stride == 1 and len(g0["srcs"]) == 1 and not pixel_shuffle and gc_wmask is None
+                  and g0["srcs"][0].dtype != torch.float32 and g0["dst"].dtype != torch.float32
+                  and g0["srcs"][0].shape[-1] % 64 == 0 and cout > 32)
+        PROFILE.append((e0, e1, flops, "mfma", name, nbytes, "conv3_lean16" if lean16 else "other"))
         return
     check(lib().fcvsr_conv2d_mfma(descs, n, mma_dtype, stream_ptr()), "fcvsr_conv2d_mfma")
 
@@ -253,7 +259,7 @@ def conv2d(srcs: Sequence[torch.Tensor], wpacked: torch.Tensor, ksize: int, cout
         e1.record()
         ho = (d.H + 2 * d.pad - d.kh) // stride + 1
         wo = (d.W + 2 * d.pad - d.kw) // stride + 1
-        PROFILE.append((e0, e1, 2.0 * d.B * ho * wo * cout * cin * ksize * ksize, "direct", name, 0))
+        PROFILE.append((e0, e1, 2.0 * d.B * ho * wo * cout * cin * ksize * ksize, "direct", name, 0, "direct"))
         return dst
     check(lib().fcvsr_conv2d(C.byref(d), stream_ptr()), "fcvsr_conv2d")
     return dst

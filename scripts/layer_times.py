@@ -17,7 +17,7 @@ with torch.no_grad():
     m(x); torch.cuda.synchronize()
 recs = hip.PROFILE; hip.PROFILE = None
 agg = collections.OrderedDict()
-for e0, e1, fl, kind, name, _nb in recs:
+for e0, e1, fl, kind, name, _nb, _var in recs:
     key = re.sub(r"body\.\d+\.body\.\d+", "body.G.body.K", name); key = re.sub(r"body\.\d+\.conv", "body.G.conv", key)
     key = re.sub(r"MConvB\.\d+", "MConvB.I", key)
     a = agg.setdefault((key, kind), [0, 0.0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1) * 1e3; a[2] += fl

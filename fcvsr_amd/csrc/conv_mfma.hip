@@ -54,6 +54,7 @@ struct MfmaArgs {
   int src16, dst16;    // sources / destination stored in the MFMA dtype (16-bit) instead of f32
   int dstbf;           // the 16-bit destination format is bf16 (generic kernel: may differ from the MFMA dtype)
   int res16;           // residual inputs stored in the MFMA dtype (lean 3x3 kernel only: 16-bit trunk)
+  int gc16;            // lean 3x3 kernel with ContextBlock fusion: the 4-couts-per-lane epilogue stores the MFMA dtype (8 bytes)
   const float* gc_wmask;   // ContextBlock fusion: per-wave online-softmax partials of the output (cout <= 64, 3x3)
   int planar;          // single f32 source with arbitrary channel stride (the NCHW frames of feat_extract), cin <= 64
   int sub2;            // stride-2 convolution: evaluate at full resolution, keep the even output pixels only
@@ -817,7 +818,8 @@ __global__ __launch_bounds__(256, NT == 128 ? 2 : 4) void conv3_lean_kernel(Mfma
               load_res<BF16, 4>(r1v.p, r1off + px * r1sx + n, r16, rr);
               x.x = fmaf(a.rs[1], rr[0], x.x); x.y = fmaf(a.rs[1], rr[1], x.y); x.z = fmaf(a.rs[1], rr[2], x.z); x.w = fmaf(a.rs[1], rr[3], x.w);
             }
-            *reinterpret_cast<float4*>(dp + px * dsx) = x;
+            if (a.gc16) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(dv.p) + drow + n + px * dsx) = cvt4<BF16>(x);
+            else *reinterpret_cast<float4*>(dp + px * dsx) = x;
           } else {
             float xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
@@ -1203,6 +1205,7 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   FCVSR_CHECK_ARG(!a.planar || (d0.src[0].dtype == FCVSR_F32 && d0.src[0].c <= 32 && d0.kh == 3),
                   "planar (channel-strided) source: one f32 source with <= 32 channels, 3x3");
   a.dst16 = d0.dst.dtype != FCVSR_F32;
+  a.gc16 = 0;
   a.dstbf = d0.dst.dtype == FCVSR_BF16;
   const bool dst_native = d0.dst.dtype == FCVSR_F32 || d0.dst.dtype == mma_dtype;   // lean kernels store f32 / MFMA dtype only
   a.n_groups = n_groups;
@@ -1312,6 +1315,14 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
     lean = lean && (!a.dst16 || d.dst.sc == 1) && ext < (1ll << 29);
     for (int q = 0; q < d.n_res; ++q)
       lean = lean && (d.res[q].dtype == FCVSR_F32 || d.res[q].sc == 1) && (!a.dst16 || d.res[q].sc == 1);
+  }
+  if (d0.gc_wmask != nullptr && a.dst16) {
+    // ContextBlock partials come out of the 4-couts-per-lane epilogue: run that variant and let it store 16-bit values
+    bool ok16 = lean && dst_native && d0.n_res == 0 && d0.cout % 4 == 0;
+    for (int g = 0; g < n_groups; ++g) ok16 = ok16 && descs[g].dst.sc == 1;
+    FCVSR_CHECK_ARG(ok16, "ContextBlock fusion with a 16-bit destination needs the lean 3x3 path, no residuals");
+    a.gc16 = 1;
+    a.dst16 = 0;
   }
   FCVSR_CHECK_ARG(!a.res16 || lean, "16-bit residuals are only supported by the lean 3x3 path");
   {

@@ -289,7 +289,7 @@ __global__ void gc_stage2_levels_kernel(GcFinishArgs a, int C, const float* w1, 
 }
 
 struct GcApplyLv {
-  const float4* r;
+  const void* r;
   const float* add;
   const void* z;
   void* out;
@@ -299,9 +299,9 @@ struct GcApplyLv {
 };
 struct GcApplyArgs { GcApplyLv lv[3]; int n; };
 
-template <int DT>
-__device__ __forceinline__ float4 gc_apply_one(const float4* r, const float* a, const void* z, void* out, long long q, float slope) {
-  const float4 rr = r[q], zz = ld4<DT>(z, q);
+template <int DT, bool R16>
+__device__ __forceinline__ float4 gc_apply_one(const void* r, const float* a, const void* z, void* out, long long q, float slope) {
+  const float4 rr = R16 ? ld4<DT>(r, q) : ld4<FCVSR_F32>(r, q), zz = ld4<DT>(z, q);
   float4 v = make_float4(rr.x + a[0], rr.y + a[1], rr.z + a[2], rr.w + a[3]);
   v.x = v.x >= 0.f ? v.x : v.x * slope; v.y = v.y >= 0.f ? v.y : v.y * slope;
   v.z = v.z >= 0.f ? v.z : v.z * slope; v.w = v.w >= 0.f ? v.w : v.w * slope;
@@ -324,7 +324,7 @@ __device__ __forceinline__ float4 as_stored(float4 v) {
   return make_float4((float)c[0], (float)c[1], (float)c[2], (float)c[3]);
 }
 
-template <int DT>
+template <int DT, bool R16>
 __global__ void gc_apply_levels_kernel(GcApplyArgs a, float slope, int Cq) {
   int li = 0;
   if (a.n > 1 && (int)blockIdx.x >= a.lv[1].blk_begin) li = 1;
@@ -341,10 +341,10 @@ __global__ void gc_apply_levels_kernel(GcApplyArgs a, float slope, int Cq) {
     const int x2 = (int)(pg % W2), y2 = (int)((pg / W2) % H2), b = (int)(pg / ((long long)W2 * H2));
     const float* ad = L.add + (long long)b * Cq * 4 + cq * 4;
     const long long q00 = (((long long)b * L.H + 2 * y2) * L.W + 2 * x2) * Cq + cq;
-    const float4 v00 = as_stored<DT>(gc_apply_one<DT>(L.r, ad, L.z, L.out, q00, slope));
-    const float4 v01 = as_stored<DT>(gc_apply_one<DT>(L.r, ad, L.z, L.out, q00 + Cq, slope));
-    const float4 v10 = as_stored<DT>(gc_apply_one<DT>(L.r, ad, L.z, L.out, q00 + (long long)L.W * Cq, slope));
-    const float4 v11 = as_stored<DT>(gc_apply_one<DT>(L.r, ad, L.z, L.out, q00 + (long long)L.W * Cq + Cq, slope));
+    const float4 v00 = as_stored<DT>(gc_apply_one<DT, R16>(L.r, ad, L.z, L.out, q00, slope));
+    const float4 v01 = as_stored<DT>(gc_apply_one<DT, R16>(L.r, ad, L.z, L.out, q00 + Cq, slope));
+    const float4 v10 = as_stored<DT>(gc_apply_one<DT, R16>(L.r, ad, L.z, L.out, q00 + (long long)L.W * Cq, slope));
+    const float4 v11 = as_stored<DT>(gc_apply_one<DT, R16>(L.r, ad, L.z, L.out, q00 + (long long)L.W * Cq + Cq, slope));
     // torch upsample_bilinear2d order: lerp along x inside each row, then along y (weights 0.5)
     const float4 top = make_float4(0.5f * v00.x + 0.5f * v01.x, 0.5f * v00.y + 0.5f * v01.y, 0.5f * v00.z + 0.5f * v01.z, 0.5f * v00.w + 0.5f * v01.w);
     const float4 bot = make_float4(0.5f * v10.x + 0.5f * v11.x, 0.5f * v10.y + 0.5f * v11.y, 0.5f * v10.z + 0.5f * v11.z, 0.5f * v10.w + 0.5f * v11.w);
@@ -353,7 +353,7 @@ __global__ void gc_apply_levels_kernel(GcApplyArgs a, float slope, int Cq) {
     const long long HWCq = (long long)L.H * L.W * Cq;
     if (t >= HWCq * L.B) return;
     const int b = (int)(t / HWCq), cq = (int)(t % Cq);
-    gc_apply_one<DT>(L.r, L.add + (long long)b * Cq * 4 + cq * 4, L.z, L.out, t, slope);
+    gc_apply_one<DT, R16>(L.r, L.add + (long long)b * Cq * 4 + cq * 4, L.z, L.out, t, slope);
   }
 }
 
@@ -513,8 +513,8 @@ extern "C" int fcvsr_gc_finish_levels(const fcvsr_gc_finish_level* lv, int n_lev
   return 0;
 }
 
-extern "C" int fcvsr_gc_apply_levels(const fcvsr_gc_apply_level* lv, int n_levels, int io_dtype, float slope, int C,
-                                     void* stream) {
+extern "C" int fcvsr_gc_apply_levels(const fcvsr_gc_apply_level* lv, int n_levels, int io_dtype, int r_dtype, float slope,
+                                     int C, void* stream) {
   FCVSR_CHECK_ARG(lv && n_levels >= 1 && n_levels <= 3, "1..3 levels");
   FCVSR_CHECK_ARG(C > 0 && C % 4 == 0, "C%4==0 required");
   FCVSR_CHECK_ARG(io_dtype == FCVSR_F32 || io_dtype == FCVSR_BF16 || io_dtype == FCVSR_F16, "bad io_dtype");
@@ -527,7 +527,7 @@ extern "C" int fcvsr_gc_apply_levels(const fcvsr_gc_apply_level* lv, int n_level
     FCVSR_CHECK_ARG(al16(s.r) && al16(s.z) && al16(s.out) && al16(s.pool), "16-byte alignment");
     FCVSR_CHECK_ARG(!s.pool || (s.H % 2 == 0 && s.W % 2 == 0), "pooled output needs even H, W");
     GcApplyLv& d = a.lv[l];
-    d.r = (const float4*)s.r; d.add = s.add; d.z = s.z; d.out = s.out; d.pool = s.pool; d.B = s.B; d.H = s.H; d.W = s.W;
+    d.r = s.r; d.add = s.add; d.z = s.z; d.out = s.out; d.pool = s.pool; d.B = s.B; d.H = s.H; d.W = s.W;
     d.blk_begin = blocks;
     if (l < n_levels) {
       const long long items = s.pool ? (long long)s.B * (s.H / 2) * (s.W / 2) * (C / 4) : (long long)s.B * s.H * s.W * (C / 4);
@@ -535,9 +535,13 @@ extern "C" int fcvsr_gc_apply_levels(const fcvsr_gc_apply_level* lv, int n_level
     }
   }
   hipStream_t st = (hipStream_t)stream;
-  if (io_dtype == FCVSR_F32) hipLaunchKernelGGL((gc_apply_levels_kernel<FCVSR_F32>), dim3(blocks), dim3(256), 0, st, a, slope, C / 4);
-  else if (io_dtype == FCVSR_BF16) hipLaunchKernelGGL((gc_apply_levels_kernel<FCVSR_BF16>), dim3(blocks), dim3(256), 0, st, a, slope, C / 4);
-  else hipLaunchKernelGGL((gc_apply_levels_kernel<FCVSR_F16>), dim3(blocks), dim3(256), 0, st, a, slope, C / 4);
+  FCVSR_CHECK_ARG(r_dtype == FCVSR_F32 || r_dtype == io_dtype, "r is f32 or stored like z/out");
+  const bool r16 = r_dtype != FCVSR_F32;
+#define FCVSR_GAL(DTV, R16V) hipLaunchKernelGGL((gc_apply_levels_kernel<DTV, R16V>), dim3(blocks), dim3(256), 0, st, a, slope, C / 4)
+  if (io_dtype == FCVSR_F32) FCVSR_GAL(FCVSR_F32, false);
+  else if (io_dtype == FCVSR_BF16) { if (r16) FCVSR_GAL(FCVSR_BF16, true); else FCVSR_GAL(FCVSR_BF16, false); }
+  else { if (r16) FCVSR_GAL(FCVSR_F16, true); else FCVSR_GAL(FCVSR_F16, false); }
+#undef FCVSR_GAL
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

@@ -454,7 +454,9 @@ class Engine:
         tdt = self._tdt()
         t2 = [like(x, n, tdt) for x in xs]
         r1 = [like(x, n, self._adt()) for x in xs]
-        rr = [like(x, n) for x in xs]
+        # RCB.body.2's output r is read once more (gc_apply): with the level-grouped tail it is stored like the trunk
+        r16 = self.precision != "f32" and tdt != torch.float32 and getattr(m, "pool_first", True)
+        rr = [like(x, n, tdt if r16 else torch.float32) for x in xs]
         self._convg(pre + ".body.0", [dict(srcs=[x], dst=t) for x, t in zip(xs, t1)], act=ACT_LEAKY, slope=0.1)
         self._convg(pre + ".body.2", [dict(srcs=[a], dst=t) for a, t in zip(t1, t2)])
         self._convg(pre + ".RCB.body.0", [dict(srcs=[a], dst=t) for a, t in zip(t2, r1)], act=ACT_LEAKY, slope=0.2)
@@ -524,7 +526,7 @@ class Engine:
             al[l].r, al[l].add, al[l].z, al[l].out = rr[l].data_ptr(), adds[l].data_ptr(), t2[l].data_ptr(), R[l].data_ptr()
             al[l].pool = P[l].data_ptr() if l < 2 else None
             al[l].B, al[l].H, al[l].W = B, xs[l].shape[1], xs[l].shape[2]
-        check(L.fcvsr_gc_apply_levels(al, 3, code, 0.2, n, st), "fcvsr_gc_apply_levels")
+        check(L.fcvsr_gc_apply_levels(al, 3, code, self._code(rr[0].dtype), 0.2, n, st), "fcvsr_gc_apply_levels")
         dn = [torch.empty_like(P[l]) for l in (0, 1)]           # dn[l] lives at level l+1's resolution
         up = [torch.empty_like(R[l]) for l in (1, 2)]
         self._convg(pre + ".down.0", [dict(srcs=[P[l]], dst=dn[l]) for l in (0, 1)])

@@ -89,7 +89,7 @@ SIGNATURES = {
     "fcvsr_gc_apply": [_VP, _VP, _VP, _VP, _I, _F, _I, _I, _I, _I, _VP],
     "fcvsr_xscale": [_VP, _VP, _F, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP],
     "fcvsr_gc_finish_levels": [C.POINTER(GcFinishLevel), _I, _VP, _VP, _I, _I, _VP],
-    "fcvsr_gc_apply_levels": [C.POINTER(GcApplyLevel), _I, _I, _F, _I, _VP],
+    "fcvsr_gc_apply_levels": [C.POINTER(GcApplyLevel), _I, _I, _I, _F, _I, _VP],
     "fcvsr_xscale_levels": [C.POINTER(XscaleLevel), _I, _I, _I, _VP],
     "fcvsr_pixel_shuffle": [_VP, _VP, _I, _I, _I, _I, _VP],
     "fcvsr_bilinear_up4": [_PV, _I, _I, _I, _PV, _VP],

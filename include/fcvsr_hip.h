@@ -185,14 +185,15 @@ typedef struct {
 int fcvsr_gc_finish_levels(const fcvsr_gc_finish_level* lv, int n_levels, const float* w1, const float* w2, int B, int C,
                            void* stream);
 typedef struct {
-  const float* r;         /* (B,H,W,C) f32 */
+  const void*  r;         /* (B,H,W,C), r_dtype: f32 or io_dtype */
   const float* add;       /* [B][C] */
   const void*  z;         /* (B,H,W,C) io_dtype */
   void*        out;       /* (B,H,W,C) io_dtype */
   void*        pool;      /* (B,H/2,W/2,C) io_dtype or NULL (needs even H, W) */
   int32_t      B, H, W;
 } fcvsr_gc_apply_level;
-int fcvsr_gc_apply_levels(const fcvsr_gc_apply_level* lv, int n_levels, int io_dtype, float slope, int C, void* stream);
+int fcvsr_gc_apply_levels(const fcvsr_gc_apply_level* lv, int n_levels, int io_dtype, int r_dtype, float slope, int C,
+                          void* stream);
 typedef struct {
   const void* x;          /* (B,H,W,C) */
   const void* r;

@@ -88,15 +88,19 @@ def test_ctypes_struct_layout_matches_header(tmp_path):
     src = tmp_path / "layout.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "fcvsr_hip.h"\n'
-        'int main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(fcvsr_view), sizeof(fcvsr_conv_desc),'
+        'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(fcvsr_view), sizeof(fcvsr_conv_desc),'
         ' offsetof(fcvsr_conv_desc, weight), offsetof(fcvsr_conv_desc, res), offsetof(fcvsr_conv_desc, dst),'
-        ' offsetof(fcvsr_conv_desc, pixel_shuffle)); return 0;}\n')
+        ' offsetof(fcvsr_conv_desc, pixel_shuffle), sizeof(fcvsr_gc_finish_level), sizeof(fcvsr_gc_apply_level),'
+        ' offsetof(fcvsr_gc_apply_level, B), sizeof(fcvsr_xscale_level), offsetof(fcvsr_xscale_level, r_scale),'
+        ' offsetof(fcvsr_xscale_level, W)); return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     D = hip.ConvDesc
     assert got == [ctypes.sizeof(hip.View), ctypes.sizeof(D), D.weight.offset, D.res.offset, D.dst.offset,
-                   D.pixel_shuffle.offset]
+                   D.pixel_shuffle.offset, ctypes.sizeof(hip.GcFinishLevel), ctypes.sizeof(hip.GcApplyLevel),
+                   hip.GcApplyLevel.B.offset, ctypes.sizeof(hip.XscaleLevel), hip.XscaleLevel.r_scale.offset,
+                   hip.XscaleLevel.W.offset]
 
 
 def test_cpu_input_raises_no_fallback():

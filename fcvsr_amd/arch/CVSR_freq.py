@@ -201,6 +201,8 @@ class _GShiftBase(nn.Module):
         self.fuse_tail = os.environ.get("FCVSR_FUSE_TAIL", "1") == "1"
         # 16-bit modes: BlockRCB's down path as conv1x1(avgpool2(R)) (they commute) and level-grouped elementwise launches
         self.pool_first = os.environ.get("FCVSR_POOL_FIRST", "1") == "1"
+        # 16-bit modes, n_features == 64: the convfuse 1x1 stack of MGAAbk as one kernel (hidden tensors stay on chip)
+        self.fuse_freq_mlp = os.environ.get("FCVSR_FUSE_FREQ_MLP", "1") == "1"
         # capture the launch sequence of a forward in a hipGraph (per input shape) and replay it
         self.use_graph = os.environ.get("FCVSR_GRAPH", "0") == "1"
 

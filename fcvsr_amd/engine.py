@@ -245,15 +245,24 @@ class Engine:
         fdt = self._adt(freq=True)
         # the offset spectra feed only convcorr.0: stored in its operand dtype (bit-identical results, half the bytes)
         off = self._new(dev, 2 * B, H, Wf, 2 * n, dtype=fdt)
-        # both directions per launch: two problem groups sharing the weights (forward: x1f vs x2f, backward: x3f vs x2f)
-        t0 = self._new(dev, 2 * B, H, Wf, 2 * n, dtype=fdt)
-        t1 = self._new(dev, 2 * B, H, Wf, 2 * n, dtype=fdt)
-        dirs = list(enumerate((x1f, x3f)))
-        self._convg("MGAA.convfuse.0", [dict(srcs=[xa, x2f], dst=t0[d * B:(d + 1) * B]) for d, xa in dirs], act=ACT_RELU,
-                    freq=True)
-        self._convg("MGAA.convfuse.2", [dict(srcs=[t0], dst=t1)], act=ACT_RELU, freq=True)
-        self._convg("MGAA.convfuse.4", [dict(srcs=[t1[d * B:(d + 1) * B]], dst=off[d * B:(d + 1) * B], res=[xa, x2f])
-                                        for d, xa in dirs], res_scale=[1.0, -1.0], freq=True)
+        fuse_mlp = fdt != torch.float32 and n == 64 and getattr(m, "fuse_freq_mlp", True)
+        if fuse_mlp:
+            # the whole convfuse stack for both directions in one kernel: hidden tensors never leave the CU
+            ws = [self._weights(f"MGAA.convfuse.{i}", torch.bfloat16)[0] for i in (0, 2, 4)]
+            P2 = C.c_void_p * 2
+            check(L.fcvsr_freq_mlp3(P2(x1f.data_ptr(), x3f.data_ptr()), P2(x2f.data_ptr(), x2f.data_ptr()), 2, 6 * n,
+                                    B * H * Wf, ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(),
+                                    P2(off[:B].data_ptr(), off[B:].data_ptr()), 2 * n, st), "fcvsr_freq_mlp3")
+        else:
+            # both directions per launch: two problem groups sharing the weights (forward: x1f vs x2f, backward: x3f vs x2f)
+            t0 = self._new(dev, 2 * B, H, Wf, 2 * n, dtype=fdt)
+            t1 = self._new(dev, 2 * B, H, Wf, 2 * n, dtype=fdt)
+            dirs = list(enumerate((x1f, x3f)))
+            self._convg("MGAA.convfuse.0", [dict(srcs=[xa, x2f], dst=t0[d * B:(d + 1) * B]) for d, xa in dirs],
+                        act=ACT_RELU, freq=True)
+            self._convg("MGAA.convfuse.2", [dict(srcs=[t0], dst=t1)], act=ACT_RELU, freq=True)
+            self._convg("MGAA.convfuse.4", [dict(srcs=[t1[d * B:(d + 1) * B]], dst=off[d * B:(d + 1) * B], res=[xa, x2f])
+                                            for d, xa in dirs], res_scale=[1.0, -1.0], freq=True)
         s0 = self._new(dev, B, H, Wf, n, dtype=fdt)
         sim = self._new(dev, B, H, Wf, 4)
         self._conv("MGAA.convcrt.0", [x2f], s0, act=ACT_RELU, freq=True)
@@ -591,7 +600,7 @@ class Engine:
             # hipGraph mode: the ~650 launches of one forward are captured once per (shape, precision, streams, weights
             # version) and replayed, which removes the host launch cost (~9 us per ctypes launch) from the critical path.
             key = (tuple(x.shape), self.precision, ns, str(dev), self._pack_epoch,
-                   tuple(bool(getattr(m, f, True)) for f in ("trunk16", "fold_f1", "fuse_tail", "pool_first")))
+                   tuple(bool(getattr(m, f, True)) for f in ("trunk16", "fold_f1", "fuse_tail", "pool_first", "fuse_freq_mlp")))
             ent = self._graphs.get(key)
             if ent is None:
                 sx = x.clone()

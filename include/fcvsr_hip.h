@@ -146,6 +146,14 @@ int fcvsr_iac_step2_fused(const fcvsr_view* prev, const fcvsr_view* off, const f
                           const float* kbias, const fcvsr_view* feat_in, float slope, int B, int H, int W,
                           const fcvsr_view* dst, void* stream);
 
+/* The whole convfuse stack (:1371-1377, applied at :1472-1474) for up to two alignment directions in one launch:
+ *   dst[d] = (xa[d] - xb[d]) + W4 . relu(W2 . relu(W0 . [xa[d] | xb[d]]))     1x1, no bias, 128 channels (n_feats = 64)
+ * xa[d], xb[d]: f32 spectra, npix pixels of 128 contiguous channels, src_pix_stride floats apart; dst[d]: bf16, 128 channels,
+ * dst_pix_stride halfwords apart; w0 [128][256], w2 / w4 [128][128] bf16 with cin contiguous (the MFMA packing of the three
+ * layers).  The two hidden tensors stay on chip. */
+int fcvsr_freq_mlp3(const float* const* xa, const float* const* xb, int n_dirs, int64_t src_pix_stride, int64_t npix,
+                    const void* w0, const void* w2, const void* w4, void* const* dst, int64_t dst_pix_stride, void* stream);
+
 /* ---- MultiFreq_Refinment pieces (CVSR_freq.py:2104-2133, :2201-2254) ---------------------------------------- */
 /* DivEnh expressions, i==0 (first=1): t=f-mean_f; e1=0.2*a*t*f+b*f.  i>0: t=f-s_f+0.2*s_o; e1 as above;
  * e2=0.2*a*s_o*f+b*f.   mode 0: write per-(b,c) sums of e1,e2 to sums[2][B][C] (two-stage, deterministic);

@@ -382,3 +382,33 @@ def test_iac_step2_fused_predictor_equals_unfused(adt, kdt):
     torch.cuda.synchronize()
     for o, r_ in zip(out, ref):
         assert torch.equal(o, r_)
+
+
+def test_freq_mlp3_matches_three_1x1_launches():
+    """The fused convfuse stack against the three stand-alone MFMA 1x1 launches (bf16 operands, f32 accumulate, hidden
+    tensors rounded to bf16 in both): identical accumulation order per layer, so the results must agree exactly."""
+    from fcvsr_amd import hip
+    L = hip.lib()
+    B, H, Wf, n = 2, 9, 23, 64                              # 414 pixels: partial last workgroup
+    spec = nhwc(_rand(B, 6 * n, H, Wf, seed=101))
+    x1f, x2f, x3f = spec[..., :2 * n], spec[..., 2 * n:4 * n], spec[..., 4 * n:]
+    dt = torch.bfloat16
+    w0 = _rand(128, 256, 1, 1, seed=102).cuda() / 16
+    w2 = _rand(128, 128, 1, 1, seed=103).cuda() / 11
+    w4 = _rand(128, 128, 1, 1, seed=104).cuda() / 11
+    p0, p2, p4 = (hip.pack_conv_weight_mfma(w, dt) for w in (w0, w2, w4))
+    ref = torch.empty(2 * B, H, Wf, 2 * n, device="cuda", dtype=dt)
+    t0 = torch.empty(2 * B, H, Wf, 2 * n, device="cuda", dtype=dt)
+    t1 = torch.empty_like(t0)
+    dirs = list(enumerate((x1f, x3f)))
+    hip.conv2d_mfma([dict(srcs=[xa, x2f], dst=t0[d * B:(d + 1) * B]) for d, xa in dirs], p0, 1, 128, hip.BF16, act=hip.ACT_RELU)
+    hip.conv2d_mfma([dict(srcs=[t0], dst=t1)], p2, 1, 128, hip.BF16, act=hip.ACT_RELU)
+    hip.conv2d_mfma([dict(srcs=[t1[d * B:(d + 1) * B]], dst=ref[d * B:(d + 1) * B], res=[xa, x2f]) for d, xa in dirs], p4, 1, 128,
+                    hip.BF16, res_scale=[1.0, -1.0])
+    out = torch.zeros_like(ref)
+    P2 = C.c_void_p * 2
+    hip.check(L.fcvsr_freq_mlp3(P2(x1f.data_ptr(), x3f.data_ptr()), P2(x2f.data_ptr(), x2f.data_ptr()), 2, 6 * n, B * H * Wf,
+                                p0.data_ptr(), p2.data_ptr(), p4.data_ptr(), P2(out[:B].data_ptr(), out[B:].data_ptr()), 2 * n,
+                                hip.stream_ptr()), "freq_mlp3")
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)

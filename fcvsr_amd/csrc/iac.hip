@@ -383,85 +383,157 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
     }
   };
 
-#pragma unroll
-  for (int dir = 0; dir < ND; ++dir) {
-  const View prev = a.d[dir].prev, off = a.d[dir].off, fin = a.d[dir].fin, dst = a.d[dir].dst;
-  Pack8<ADT> fpk[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int p = j * 32 + ps;
-    int gy = ty0 + (p >> 4), gx = tx0 + (p & 15);
-    gy = gy > H - 1 ? H - 1 : gy;
-    gx = gx > W - 1 ? W - 1 : gx;
-    fpk[j] = ld_p8<ADT>(fin.p, (long long)b * fin.sb + (long long)gy * fin.sy + (long long)gx * fin.sx + c0);
-  }
-  // ---- phase 1: s = flow_warp(prev, off) on the halo tile (coordinates clamped = replicate padding of s) -------------
-  // Staged so that the loads batch: all offsets, then all 4 x NP bilinear taps (unconditional: out-of-image taps read a
-  // clamped address with weight 0, which is what the zero padding of flow_warp amounts to), then the arithmetic.
-  const long long pp = (long long)b * prev.sb + c0;
+  // ---- software pipeline over the (up to two) directions: every load of direction 1 that does not depend on LDS is in
+  // flight while direction 0 runs its LDS phases -------------------------------------------------------------------------
   constexpr int NP = (kIHY * kIHX + 31) / 32;
-  float ox[NP], oy[NP];
-  int cgx[NP], cgy[NP];
+  int cgx[NP], cgy[NP];                                // clamped coordinates of the lane's halo pixels (direction-independent)
 #pragma unroll
   for (int it = 0; it < NP; ++it) {
     int hp = it * 32 + ps;
     hp = hp < kIHY * kIHX ? hp : kIHY * kIHX - 1;
     const int hy = hp / kIHX, hx = hp - hy * kIHX;
     int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-    gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
-    gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
-    const float* op = off.p + (long long)b * off.sb + (long long)gy * off.sy + (long long)gx * off.sx;
-    ox[it] = op[0];
-    oy[it] = op[off.sc];
-    cgx[it] = gx;
-    cgy[it] = gy;
+    cgy[it] = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
+    cgx[it] = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
   }
-  if (FK && dir == 0) predictor_gemm();                // operands requested above, together with the offsets
-  Pack8<ADT> tap[NP][4];
-  float tw[NP][4];
+  float ox[ND][NP], oy[ND][NP];
+  Pack8<ADT> fpk[ND][2];
 #pragma unroll
-  for (int it = 0; it < NP; ++it) {
-    const float fx = (float)cgx[it] + ox[it];
-    const float fy = (float)cgy[it] + oy[it];
-    const float x0f = floorf(fx), y0f = floorf(fy);
-    const float wx1 = fx - x0f, wy1 = fy - y0f;
-    const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-    const bool sane = (fx > -2.f) && (fx < (float)W + 1.f) && (fy > -2.f) && (fy < (float)H + 1.f);
-    const int x0 = sane ? (int)x0f : -4, y0 = sane ? (int)y0f : -4;
+  for (int dir = 0; dir < ND; ++dir) {
+    const View off = a.d[dir].off, fin = a.d[dir].fin;
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
+    for (int it = 0; it < NP; ++it) {
+      const float* op = off.p + (long long)b * off.sb + (long long)cgy[it] * off.sy + (long long)cgx[it] * off.sx;
+      ox[dir][it] = op[0];
+      oy[dir][it] = op[off.sc];
+    }
 #pragma unroll
-      for (int dx = 0; dx < 2; ++dx) {
-        const int xi = x0 + dx, yi = y0 + dy;
-        const bool in = xi >= 0 && xi < W && yi >= 0 && yi < H;
-        const int xc = xi < 0 ? 0 : (xi > W - 1 ? W - 1 : xi), yc = yi < 0 ? 0 : (yi > H - 1 ? H - 1 : yi);
-        tw[it][dy * 2 + dx] = in ? (dy ? wy1 : wy0) * (dx ? wx1 : wx0) : 0.f;
-        tap[it][dy * 2 + dx] = ld_p8<ADT>(prev.p, pp + (long long)yc * prev.sy + (long long)xc * prev.sx);
+    for (int j = 0; j < 2; ++j) {
+      const int p = j * 32 + ps;
+      int gy = ty0 + (p >> 4), gx = tx0 + (p & 15);
+      gy = gy > H - 1 ? H - 1 : gy;
+      gx = gx > W - 1 ? W - 1 : gx;
+      fpk[dir][j] = ld_p8<ADT>(fin.p, (long long)b * fin.sb + (long long)gy * fin.sy + (long long)gx * fin.sx + c0);
+    }
+  }
+  if (FK) predictor_gemm();                            // operands requested above, together with the offsets
+
+  // phase 1a: the 4 x NP bilinear taps of a direction (unconditional: out-of-image taps read a clamped address with
+  // weight 0, which is what the zero padding of flow_warp amounts to)
+  Pack8<ADT> tap[ND][NP][4];
+  float tw[ND][NP][4];
+  auto issue_taps = [&](const int dir) {
+    const View prev = a.d[dir].prev;
+    const long long pp = (long long)b * prev.sb + c0;
+    const float* pb = ADT == FCVSR_F32 ? prev.p + pp
+                                       : reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(prev.p) + pp);
+    const int psy = (int)prev.sy, psx = (int)prev.sx;   // 32-bit offsets inside one image (host checks H*sy < 2^31)
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const float fx = (float)cgx[it] + ox[dir][it];
+      const float fy = (float)cgy[it] + oy[dir][it];
+      const float x0f = floorf(fx), y0f = floorf(fy);
+      const float wx1 = fx - x0f, wy1 = fy - y0f;
+      const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+      const bool sane = (fx > -2.f) && (fx < (float)W + 1.f) && (fy > -2.f) && (fy < (float)H + 1.f);
+      const int x0 = sane ? (int)x0f : -4, y0 = sane ? (int)y0f : -4;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int xi = x0 + dx, yi = y0 + dy;
+          const bool in = xi >= 0 && xi < W && yi >= 0 && yi < H;
+          const int xc = xi < 0 ? 0 : (xi > W - 1 ? W - 1 : xi), yc = yi < 0 ? 0 : (yi > H - 1 ? H - 1 : yi);
+          tw[dir][it][dy * 2 + dx] = in ? (dy ? wy1 : wy0) * (dx ? wx1 : wx0) : 0.f;
+          const int eo = yc * psy + xc * psx;
+          tap[dir][it][dy * 2 + dx] = ld_p8<ADT>(pb, eo);
+        }
       }
     }
-  }
+  };
+  // phase 1b: s = flow_warp(prev, off) on the halo tile (coordinates clamped = replicate padding of s)
+  auto warp_store = [&](const int dir) {
 #pragma unroll
-  for (int it = 0; it < NP; ++it) {
-    const int hp = it * 32 + ps;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < NP; ++it) {
+      const int hp = it * 32 + ps;
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float v[8];
-      unpack8<ADT>(tap[it][q], v);
-      // an out-of-image tap must contribute exactly 0 even if the clamped sample is Inf/NaN
-      const float w = tw[it][q];
+      for (int q = 0; q < 4; ++q) {
+        float v[8];
+        unpack8<ADT>(tap[dir][it][q], v);
+        // out-of-image taps carry weight 0 (their clamped sample is a finite in-image value)
+        const float w = tw[dir][it][q];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) acc[c] = w != 0.f ? fmaf(v[c], w, acc[c]) : acc[c];
+        for (int c = 0; c < 8; ++c) acc[c] = fmaf(v[c], w, acc[c]);
+      }
+      if (hp < kIHY * kIHX) {
+        float* sp = s_s + hp * kJC + oct * 8;
+        *reinterpret_cast<float4*>(sp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(sp + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+      }
     }
-    if (hp < kIHY * kIHX) {
-      float* sp = s_s + hp * kJC + oct * 8;
-      *reinterpret_cast<float4*>(sp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-      *reinterpret_cast<float4*>(sp + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  };
+  // phases 2 and 3 of a direction (s_s complete on entry)
+  auto sac_phases = [&](const int dir) {
+    const View dst = a.d[dir].dst;
+    // ---- phase 2: v[y][hx] = sum_t s[y+t][hx] * K1[y][clamp(hx)][c*3+t] -------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      int y, hx;
+      if (j < 2) { const int p = j * 32 + ps; y = p >> 4; hx = (p & 15) + 1; }
+      else { y = ps >> 1; hx = (ps & 1) ? kIHX - 1 : 0; }
+      if (j < 2 || ps < 8) {
+        float k[24];
+        unpack_k24<KDT>(j < 2 ? kin[j] : khal, k);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+          const float* sp = s_s + ((y + tt) * kIHX + hx) * kJC + oct * 8;
+          const float4 va = *reinterpret_cast<const float4*>(sp), vb = *reinterpret_cast<const float4*>(sp + 4);
+          const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+          for (int c = 0; c < 8; ++c) acc[c] = fmaf(v[c], k[c * 3 + tt], acc[c]);
+        }
+        float* vp = v_s + (y * kIHX + hx) * kJC + oct * 8;
+        *reinterpret_cast<float4*>(vp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(vp + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+      }
     }
-  }
-  __syncthreads();
+    __syncthreads();
+    // ---- phase 3: out = lrelu( sum_t v[y][x+t] * K1[y][x][c*3+t] + feat_in ) ----------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int p = j * 32 + ps;
+      const int y = p >> 4, x = p & 15;
+      const int gy = ty0 + y, gx = tx0 + x;
+      if (gy < H && gx < W) {
+        float k[24], f[8];
+        unpack_k24<KDT>(kin[j], k);
+        unpack8<ADT>(fpk[dir][j], f);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+          const float* vp = v_s + (y * kIHX + x + tt) * kJC + oct * 8;
+          const float4 va = *reinterpret_cast<const float4*>(vp), vb = *reinterpret_cast<const float4*>(vp + 4);
+          const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+          for (int c = 0; c < 8; ++c) acc[c] = fmaf(v[c], k[c * 3 + tt], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          acc[c] += f[c];
+          acc[c] = acc[c] >= 0.f ? acc[c] : acc[c] * slope;
+        }
+        st_p8<ADT>(dst.p, (long long)b * dst.sb + (long long)gy * dst.sy + (long long)gx * dst.sx + c0, acc);
+      }
+    }
+  };
 
-  if (FK && dir == 0) {                                // the predicted kernels of the lane's pixels: LDS -> registers, once
+  issue_taps(0);
+  warp_store(0);
+  if (ND > 1) issue_taps(1);                           // in flight during direction 0's LDS phases
+  __syncthreads();
+  if (FK) {                                            // the predicted kernels of the lane's pixels: LDS -> registers, once
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int p = j * 32 + ps;
@@ -473,59 +545,13 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
       khal.q[0] = kq[0]; khal.q[1] = kq[1]; khal.q[2] = kq[2];
     }
   }
-  // ---- phase 2: v[y][hx] = sum_t s[y+t][hx] * K1[y][clamp(hx)][c*3+t] ---------------------------------------------------
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    int y, hx;
-    if (j < 2) { const int p = j * 32 + ps; y = p >> 4; hx = (p & 15) + 1; }
-    else { y = ps >> 1; hx = (ps & 1) ? kIHX - 1 : 0; }
-    if (j < 2 || ps < 8) {
-      float k[24];
-      unpack_k24<KDT>(j < 2 ? kin[j] : khal, k);
-      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int tt = 0; tt < 3; ++tt) {
-        const float* sp = s_s + ((y + tt) * kIHX + hx) * kJC + oct * 8;
-        const float4 va = *reinterpret_cast<const float4*>(sp), vb = *reinterpret_cast<const float4*>(sp + 4);
-        const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] = fmaf(v[c], k[c * 3 + tt], acc[c]);
-      }
-      float* vp = v_s + (y * kIHX + hx) * kJC + oct * 8;
-      *reinterpret_cast<float4*>(vp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-      *reinterpret_cast<float4*>(vp + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
-    }
+  sac_phases(0);
+  if (ND > 1) {
+    // s_s was last read in phase 2 of direction 0, which every wave has left (barrier inside sac_phases)
+    warp_store(1);
+    __syncthreads();
+    sac_phases(1);
   }
-  __syncthreads();
-
-  // ---- phase 3: out = lrelu( sum_t v[y][x+t] * K1[y][x][c*3+t] + feat_in ) ------------------------------------------------
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int p = j * 32 + ps;
-    const int y = p >> 4, x = p & 15;
-    const int gy = ty0 + y, gx = tx0 + x;
-    if (gy < H && gx < W) {
-      float k[24], f[8];
-      unpack_k24<KDT>(kin[j], k);
-      unpack8<ADT>(fpk[j], f);
-      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int tt = 0; tt < 3; ++tt) {
-        const float* vp = v_s + (y * kIHX + x + tt) * kJC + oct * 8;
-        const float4 va = *reinterpret_cast<const float4*>(vp), vb = *reinterpret_cast<const float4*>(vp + 4);
-        const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] = fmaf(v[c], k[c * 3 + tt], acc[c]);
-      }
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        acc[c] += f[c];
-        acc[c] = acc[c] >= 0.f ? acc[c] : acc[c] * slope;
-      }
-      st_p8<ADT>(dst.p, (long long)b * dst.sb + (long long)gy * dst.sy + (long long)gx * dst.sx + c0, acc);
-    }
-  }
-  }   // direction
 }
 
 }  // namespace fcvsr
@@ -583,7 +609,8 @@ extern "C" int fcvsr_iac_step(const fcvsr_view* prev, const fcvsr_view* off, con
   static const bool no_wide = getenv("FCVSR_IAC_WIDE") && atoi(getenv("FCVSR_IAC_WIDE")) == 0;
   const int fa = adt == FCVSR_F32 ? 4 : 8;
   auto wide_ok = [&](const fcvsr_view* v) { return ((uintptr_t)v->ptr % 16) == 0 && v->sx % fa == 0 && v->sy % fa == 0 && v->sb % fa == 0; };
-  const bool wide = !no_wide && prev->c % kJC == 0 && wide_ok(prev) && wide_ok(feat_in) && wide_ok(dst);
+  const bool wide = !no_wide && prev->c % kJC == 0 && wide_ok(prev) && wide_ok(feat_in) && wide_ok(dst) &&
+                    (long long)H * prev->sy < (1ll << 31);
   dim3 grid(B * tx * ty, prev->c / (wide ? kJC : kIC));
   hipStream_t st = (hipStream_t)stream;
   const View pv = to_view(*prev), ov = to_view(*off), kv = to_view(*k1), fv = to_view(*feat_in), dv = to_view(*dst);
@@ -653,6 +680,7 @@ extern "C" int fcvsr_iac_step2_fused(const fcvsr_view* prev, const fcvsr_view* o
                   "k0: 64 contiguous 16-bit channels, 16-byte aligned");
   FCVSR_CHECK_ARG(((uintptr_t)wk % 16) == 0 && ((uintptr_t)kbias % 16) == 0, "weights / bias must be 16-byte aligned");
   FCVSR_CHECK_ARG(B > 0 && H > 0 && W > 0, "bad sizes");
+  FCVSR_CHECK_ARG((long long)H * prev[0].sy < (1ll << 31) && (long long)H * prev[1].sy < (1ll << 31), "image too large");
   const int tx = cdiv(W, kIX), ty = cdiv(H, kIY);
   dim3 grid(B * tx * ty, 1);
   IacArgs a;

@@ -56,6 +56,43 @@ __global__ void divenh_apply_kernel(DivEnhExprF ex, float* s_f, float* s_o, cons
   else { s_f[t] += fv; s_o[t] += o; }
 }
 
+// apply step of band i fused with the reduction that the NEXT step needs (same partition and order as reduce_stage1 on
+// DivEnhExprF, so the sums are bit-identical to the two-kernel sequence): the running sums s_f, s_o are read and written
+// once instead of being read again by a separate reduction pass.
+struct DivEnhApplyNextF {
+  DivEnhExprF ex;          // band i (f, s_f, s_o, a, b, mean, first)
+  float* s_f;
+  float* s_o;
+  const float* g1;
+  const float* g2;
+  const float* f_next;     // band i+1 (next_kind 0)
+  const float* a_next;
+  const float* b_next;
+  int next_kind;           // 0: e1, e2 of band i+1;  1: (new s_o, 0) = channel sums for the final CALayer
+  __device__ void operator()(int bi, long long p, int c, float* out) const {
+    const long long i = ((long long)bi * ex.HW + p) * ex.C + c;
+    float e1, e2, fv;
+    ex.eval(bi, p, c, e1, e2, fv);
+    float o = e1 * g1[bi * ex.C + c];
+    if (!ex.first) o += e2 * g2[bi * ex.C + c];
+    float nf, no;
+    if (ex.first) { nf = fv; no = o; }
+    else { nf = s_f[i] + fv; no = s_o[i] + o; }
+    s_f[i] = nf;
+    s_o[i] = no;
+    if (next_kind == 0) {
+      const float fn = f_next[i];
+      const float aa = 0.2f * a_next[c], bb = b_next[c];
+      const float t = fn - nf + 0.2f * no;
+      out[0] = aa * t * fn + bb * fn;
+      out[1] = aa * no * fn + bb * fn;
+    } else {
+      out[0] = no;
+      out[1] = 0.f;
+    }
+  }
+};
+
 template <int XD>
 __device__ __forceinline__ float4 ld_x4(const void* base, long long quad) {
   if (XD == FCVSR_F32) return reinterpret_cast<const float4*>(base)[quad];
@@ -117,6 +154,27 @@ extern "C" int fcvsr_divenh(int mode, int first, const float* f, float* s_f, flo
     hipLaunchKernelGGL(divenh_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, ex, s_f, s_o, g1, g2, B);
     FCVSR_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+extern "C" int fcvsr_divenh_apply_next(int first, const float* f, float* s_f, float* s_o, const float* a, const float* b,
+                                       const float* mean_f_sum, float inv_hw, const float* g1, const float* g2,
+                                       const float* f_next, const float* a_next, const float* b_next, float* sums,
+                                       float* scratch, int64_t scratch_elems, int B, int H, int W, int C, void* stream) {
+  FCVSR_CHECK_ARG(f && s_f && s_o && a && b && g1 && (first || g2) && sums && scratch, "null pointer");
+  FCVSR_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C <= 256, "bad sizes");
+  FCVSR_CHECK_ARG(!first || mean_f_sum, "first block needs the sums of f");
+  FCVSR_CHECK_ARG((f_next == nullptr) == (a_next == nullptr) && (f_next == nullptr) == (b_next == nullptr), "next band: all or none");
+  DivEnhApplyNextF ex{{f, s_f, s_o, a, b, mean_f_sum, inv_hw, (long long)H * W, C, first}, s_f, s_o, g1, g2, f_next, a_next,
+                      b_next, f_next ? 0 : 1};
+  const long long HW = (long long)H * W;
+  const int nblk = red_blocks(HW);
+  FCVSR_CHECK_ARG(scratch_elems >= 2ll * B * nblk * C, "scratch too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((reduce_stage1<2, DivEnhApplyNextF>), dim3(nblk, B), dim3(kRedThreads), 0, st, ex, B, HW, C, scratch);
+  FCVSR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_stage2, dim3(2 * B), dim3(kRedThreads), 0, st, (const float*)scratch, 2 * B, nblk, C, sums);
+  FCVSR_LAUNCH_CHECK();
   return 0;
 }
 

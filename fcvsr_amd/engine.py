@@ -426,19 +426,28 @@ class Engine:
         sums = self._new(dev, 2, B, n)
         inv_hw = 1.0 / (H * W)
         mean_sum = self._channel_sum(freq[0])
+        # reduce(0); then per band: gates from the current sums, apply fused with the reduction the NEXT step needs (the
+        # next band's e1/e2 sums, or the channel sums of s_o for the final CALayer) - s_f, s_o make one round trip per band
+        ab = [(par[f"MFFRblock.DivEnh_block.{i}.a"], par[f"MFFRblock.DivEnh_block.{i}.b"]) for i in range(Q)]
+        check(L.fcvsr_divenh(0, 1, freq[0].data_ptr(), s_f.data_ptr(), s_o.data_ptr(), ab[0][0].data_ptr(),
+                             ab[0][1].data_ptr(), mean_sum.data_ptr(), inv_hw, None, None, sums.data_ptr(),
+                             scratch.data_ptr(), scratch.numel(), B, H, W, n, st), "fcvsr_divenh(reduce)")
         for i in range(Q):
             pre = f"MFFRblock.DivEnh_block.{i}"
-            a, b = par[pre + ".a"], par[pre + ".b"]
+            a, b = ab[i]
             first = 1 if i == 0 else 0
-            check(L.fcvsr_divenh(0, first, freq[i].data_ptr(), s_f.data_ptr(), s_o.data_ptr(), a.data_ptr(),
-                                 b.data_ptr(), mean_sum.data_ptr(), inv_hw, None, None, sums.data_ptr(),
-                                 scratch.data_ptr(), scratch.numel(), B, H, W, n, st), "fcvsr_divenh(reduce)")
             g1 = self._ca_gate(sums[0], inv_hw, pre + ".ca", B, n)
             g2 = self._ca_gate(sums[1], inv_hw, pre + ".ca", B, n) if i > 0 else None
-            check(L.fcvsr_divenh(1, first, freq[i].data_ptr(), s_f.data_ptr(), s_o.data_ptr(), a.data_ptr(),
-                                 b.data_ptr(), mean_sum.data_ptr(), inv_hw, g1.data_ptr(), ptr(g2), None, None, 0,
-                                 B, H, W, n, st), "fcvsr_divenh(apply)")
-        g = self._ca_gate(self._channel_sum(s_o), inv_hw, "MFFRblock.ca", B, n)
+            sums = self._new(dev, 2, B, n)                        # the gates above were computed from the previous buffer
+            nxt = i + 1 < Q
+            check(L.fcvsr_divenh_apply_next(first, freq[i].data_ptr(), s_f.data_ptr(), s_o.data_ptr(), a.data_ptr(),
+                                            b.data_ptr(), mean_sum.data_ptr(), inv_hw, g1.data_ptr(), ptr(g2),
+                                            freq[i + 1].data_ptr() if nxt else None,
+                                            ab[i + 1][0].data_ptr() if nxt else None,
+                                            ab[i + 1][1].data_ptr() if nxt else None, sums.data_ptr(),
+                                            scratch.data_ptr(), scratch.numel(), B, H, W, n, st),
+                  "fcvsr_divenh_apply_next")
+        g = self._ca_gate(sums[0], inv_hw, "MFFRblock.ca", B, n)
         out = self._new(dev, B, H, W, n, dtype=out_dtype)
         check(L.fcvsr_scale_add(s_o.data_ptr(), g.data_ptr(), x.data_ptr(), self._code(x.dtype), out.data_ptr(),
                                 self._code(out_dtype), B, H, W, n, st), "fcvsr_scale_add")

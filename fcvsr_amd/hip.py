@@ -84,6 +84,7 @@ SIGNATURES = {
     "fcvsr_iac_step2": [_PV, _PV, _PV, _PV, _F, _I, _I, _I, _PV, _VP],
     "fcvsr_iac_step2_fused": [_PV, _PV, _PV, _VP, _VP, _PV, _F, _I, _I, _I, _PV, _VP],
     "fcvsr_divenh": [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _F, _VP, _VP, _VP, _VP, _I64, _I, _I, _I, _I, _VP],
+    "fcvsr_divenh_apply_next": [_I, _VP, _VP, _VP, _VP, _VP, _VP, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _I, _I, _I, _I, _VP],
     "fcvsr_scale_add": [_VP, _VP, _VP, _I, _VP, _I, _I, _I, _I, _I, _VP],
     "fcvsr_gc_context": [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _I64, _VP],
     "fcvsr_gc_finish": [_VP, _I, _VP, _VP, _I, _I, _VP, _VP],

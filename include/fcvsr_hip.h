@@ -161,6 +161,13 @@ int fcvsr_freq_mlp3(const float* const* xa, const float* const* xb, int n_dirs, 
 int fcvsr_divenh(int mode, int first, const float* f, float* s_f, float* s_o, const float* a, const float* b,
                  const float* mean_f_sum, float inv_hw, const float* g1, const float* g2,
                  float* sums, float* scratch, int64_t scratch_elems, int B, int H, int W, int C, void* stream);
+/* mode 1 of fcvsr_divenh for band i fused with the reduction the next step needs (s_f, s_o are touched once):
+ *   f_next != NULL: sums[2][B][C] = per-(b,c) sums of e1, e2 of band i+1 (= mode 0 of the next block, bit-identical);
+ *   f_next == NULL: sums[0][B][C] = per-(b,c) sums of the updated s_o (input of the final CALayer), sums[1] = 0. */
+int fcvsr_divenh_apply_next(int first, const float* f, float* s_f, float* s_o, const float* a, const float* b,
+                            const float* mean_f_sum, float inv_hw, const float* g1, const float* g2,
+                            const float* f_next, const float* a_next, const float* b_next, float* sums,
+                            float* scratch, int64_t scratch_elems, int B, int H, int W, int C, void* stream);
 /* out = z*gate[b][c] + x   (final CALayer of MFFR, :2229-2230); x read as x_dtype, out stored as out_dtype */
 int fcvsr_scale_add(const float* z, const float* gate, const void* x, int x_dtype, void* out, int out_dtype, int B, int H,
                     int W, int C, void* stream);

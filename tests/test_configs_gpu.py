@@ -66,3 +66,30 @@ def test_config4_reds4_shaped_streaming_batch_independence():
     model.streams = 2
     c = super_resolve_sequence(model, lr, batch=3, centres=[0, 4, 9])
     assert np.array_equal(b, c)                            # multi-stream execution is bit-identical
+
+
+def test_config1_bench_shape_against_oracle():
+    """BASELINE config 1 at its real size (S model, 7x180x320 -> 720x1280, the shape bench.py times): exact-f32 mode within
+    1e-4 of the CPU oracle, the bench default (bf16 operands, 16-bit activation storage, every fused kernel on) and f16
+    within the 0.01 dB budget.  180 rows / 161 spectrum columns exercise the partial tiles of every kernel."""
+    from fcvsr_amd.arch.CVSR_freq import GShiftNet_S
+    from fcvsr_amd.arch.schema import state_dict_shapes
+    from fcvsr_amd.weights import synthetic_state_dict
+    from oracle import fcvsr_oracle as O
+    sd = synthetic_state_dict(state_dict_shapes("GShiftNet_S"))
+    model = GShiftNet_S()
+    model.load_state_dict(sd)
+    model = model.cuda()
+    x = _smooth_video(7, 180, 320, seed=7)[None]              # (1,7,1,H,W): one CPU oracle forward takes about a minute
+    with torch.no_grad():
+        ref = O.forward(sd, x)
+        model.precision = "f32"
+        y32 = model(x.cuda()).cpu()
+        assert float((y32 - ref).abs().max()) <= 1e-4
+        for prec, min_psnr in (("bf16", 70.0), ("f16", 88.0)):
+            model.precision = prec
+            y = model(x.cuda()).cpu()
+            mse = float(((y.double() - ref.double()) * 255).pow(2).mean())
+            psnr = 20 * np.log10(255 / np.sqrt(mse))
+            assert psnr >= min_psnr, (prec, psnr)
+            assert 10 * np.log10(1 + 10 ** ((30.0 - psnr) / 10)) < 0.01

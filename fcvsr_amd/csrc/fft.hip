@@ -179,6 +179,17 @@ __device__ __forceinline__ int run_stages(float* lds, const FftPlan& plan, int L
   return cur;
 }
 
+// Workgroup id -> (line, chunk) such that the channel chunks of one image line (which read / write the same 128-byte memory
+// lines) run on ONE XCD: ids go round-robin to the 8 XCDs, so inside a group of 8 lines x nchunk workgroups id % 8 selects
+// the line and id / 8 the chunk.  The host rounds the line count (gridDim.y) up to a multiple of 8.
+__device__ __forceinline__ void xcd_line_chunk(int* line, int* chunk) {
+  const int nchunk = gridDim.x;
+  const int lin = blockIdx.y * nchunk + blockIdx.x;
+  const int grp = lin / (8 * nchunk), rem = lin - grp * (8 * nchunk);
+  *line = grp * 8 + (rem & 7);
+  *chunk = rem >> 3;
+}
+
 // ---- forward rows: real (B,H,W,n) -> half spectrum, two channels per complex lane -------------------------------
 __device__ __forceinline__ float ld_act(const float* base, long long idx, int dt) {
   if (dt == FCVSR_F32) return base[idx];
@@ -200,11 +211,14 @@ __device__ __forceinline__ float4 ld_act4(const float* base, long long idx, int 
 
 // `vec`: every channel of the workgroup's chunk exists and all offsets are 4-channel aligned -> 16-byte accesses
 __global__ __launch_bounds__(512) void rfft_rows_kernel(View src, int src_dt, int n, int H, int W, int L, float* spec,
-                                                        long long ps, int im_off, int re_off, FftPlan plan, int vec) {
+                                                        long long ps, int im_off, int re_off, FftPlan plan, int vec, int nbatch) {
   extern __shared__ __align__(16) float lds[];
   const int NL = W * L;
-  const int b = blockIdx.y / H, y = blockIdx.y % H;
-  const int c0 = blockIdx.x * 2 * L;   // channel chunks of one row are dispatched together (they share 128-byte lines)
+  int row, chunk;
+  xcd_line_chunk(&row, &chunk);
+  const int b = row / H, y = row % H;
+  if (b >= nbatch) return;                              // padding lines of the rounded-up grid
+  const int c0 = chunk * 2 * L;
   const int Wf = W / 2 + 1;
   make_twiddles(lds + 4 * NL, W, false);
   const long long sp = (long long)b * src.sb + (long long)y * src.sy;
@@ -263,11 +277,14 @@ __global__ __launch_bounds__(512) void rfft_rows_kernel(View src, int src_dt, in
 // ---- columns: complex length-H transform of spectrum columns, forward or inverse, optional real mask -----------
 __global__ __launch_bounds__(512) void fft_cols_kernel(const float* in, float* out, long long ps, int im_off, int re_off,
                                                        int n, int H, int Wf, int L, int inverse, const float* mask,
-                                                       FftPlan plan, int vec) {
+                                                       FftPlan plan, int vec, int nbatch) {
   extern __shared__ __align__(16) float lds[];
   const int NL = H * L;
-  const int b = blockIdx.y / Wf, kx = blockIdx.y % Wf;
-  const int c0 = blockIdx.x * L;
+  int col, chunk;
+  xcd_line_chunk(&col, &chunk);
+  const int b = col / Wf, kx = col % Wf;
+  if (b >= nbatch) return;
+  const int c0 = chunk * L;
   make_twiddles(lds + 4 * NL, H, inverse != 0);
   const int logL = 31 - __clz(L);
   if (vec) {
@@ -317,11 +334,15 @@ __global__ __launch_bounds__(512) void fft_cols_kernel(const float* in, float* o
 
 // ---- inverse rows: half spectrum -> real (c2r semantics: imag of DC / Nyquist ignored), two channels per lane ----
 __global__ __launch_bounds__(512) void irfft_rows_kernel(const float* spec, long long ps, int im_off, int re_off, int n,
-                                                         int H, int W, int L, View dst, float scale, FftPlan plan, int vec) {
+                                                         int H, int W, int L, View dst, float scale, FftPlan plan, int vec,
+                                                         int nbatch) {
   extern __shared__ __align__(16) float lds[];
   const int NL = W * L;
-  const int b = blockIdx.y / H, y = blockIdx.y % H;
-  const int c0 = blockIdx.x * 2 * L;   // channel chunks of one row are dispatched together (they share 128-byte lines)
+  int row, chunk;
+  xcd_line_chunk(&row, &chunk);
+  const int b = row / H, y = row % H;
+  if (b >= nbatch) return;
+  const int c0 = chunk * 2 * L;
   const int Wf = W / 2 + 1;
   make_twiddles(lds + 4 * NL, W, true);
   const float* ip = spec + ((long long)(b * H + y) * Wf) * ps;
@@ -423,12 +444,12 @@ extern "C" int fcvsr_rfft2(const fcvsr_view* src, int B, int H, int W, int n, fl
     FCVSR_CHECK_ARG(16ll * W * L + 8ll * W <= 160 * 1024, "row too long for LDS");
     const size_t lds = 16ull * W * L + 8ull * W;
     (void)allow_lds(rfft_rows_kernel, lds);
-    dim3 grid(cdiv(n, 2 * L), B * H);
+    dim3 grid(cdiv(n, 2 * L), (B * H + 7) / 8 * 8);    // rows rounded up: the kernel remaps ids in groups of 8 rows
     const int sal = src->dtype == FCVSR_F32 ? 16 : 8;
     const int vec = (L >= 4 && n % (2 * L) == 0 && src->sc == 1 && src->sx % 4 == 0 && src->sy % 4 == 0 && src->sb % 4 == 0 &&
                      ((uintptr_t)src->ptr % sal) == 0 && spec_ok) ? 1 : 0;
     hipLaunchKernelGGL(rfft_rows_kernel, grid, dim3(512), lds, st, to_view(*src), (int)src->dtype, n, H, W, L, spec,
-                       (long long)pix_stride, im_off, re_off, pw, vec);
+                       (long long)pix_stride, im_off, re_off, pw, vec, B);
     FCVSR_LAUNCH_CHECK();
   }
   {
@@ -436,10 +457,10 @@ extern "C" int fcvsr_rfft2(const fcvsr_view* src, int B, int H, int W, int n, fl
     FCVSR_CHECK_ARG(16ll * H * L + 8ll * H <= 160 * 1024, "column too long for LDS");
     const size_t lds = 16ull * H * L + 8ull * H;
     (void)allow_lds(fft_cols_kernel, lds);
-    dim3 grid(cdiv(n, L), B * Wf);
+    dim3 grid(cdiv(n, L), (B * Wf + 7) / 8 * 8);
     const int vec = (L >= 4 && n % L == 0 && spec_ok) ? 1 : 0;
     hipLaunchKernelGGL(fft_cols_kernel, grid, dim3(512), lds, st, (const float*)spec, spec, (long long)pix_stride, im_off,
-                       re_off, n, H, Wf, L, 0, (const float*)nullptr, ph, vec);
+                       re_off, n, H, Wf, L, 0, (const float*)nullptr, ph, vec, B);
     FCVSR_LAUNCH_CHECK();
   }
   return 0;
@@ -461,10 +482,10 @@ extern "C" int fcvsr_irfft2(const float* spec, int64_t pix_stride, int im_off, i
     FCVSR_CHECK_ARG(16ll * H * L + 8ll * H <= 160 * 1024, "column too long for LDS");
     const size_t lds = 16ull * H * L + 8ull * H;
     (void)allow_lds(fft_cols_kernel, lds);
-    dim3 grid(cdiv(n, L), B * Wf);
+    dim3 grid(cdiv(n, L), (B * Wf + 7) / 8 * 8);
     const int vec = (L >= 4 && n % L == 0 && spec_ok && ((uintptr_t)mid % 16) == 0) ? 1 : 0;
     hipLaunchKernelGGL(fft_cols_kernel, grid, dim3(512), lds, st, spec, mid, (long long)pix_stride, im_off, re_off, n, H,
-                       Wf, L, 1, mask, ph, vec);
+                       Wf, L, 1, mask, ph, vec, B);
     FCVSR_LAUNCH_CHECK();
   }
   {
@@ -472,11 +493,11 @@ extern "C" int fcvsr_irfft2(const float* spec, int64_t pix_stride, int im_off, i
     FCVSR_CHECK_ARG(16ll * W * L + 8ll * W <= 160 * 1024, "row too long for LDS");
     const size_t lds = 16ull * W * L + 8ull * W;
     (void)allow_lds(irfft_rows_kernel, lds);
-    dim3 grid(cdiv(n, 2 * L), B * H);
+    dim3 grid(cdiv(n, 2 * L), (B * H + 7) / 8 * 8);
     const int vec = (L >= 4 && n % (2 * L) == 0 && spec_ok && ((uintptr_t)mid % 16) == 0 && dst->sc == 1 && dst->sx % 4 == 0 &&
                      dst->sy % 4 == 0 && dst->sb % 4 == 0 && ((uintptr_t)dst->ptr % 16) == 0) ? 1 : 0;
     hipLaunchKernelGGL(irfft_rows_kernel, grid, dim3(512), lds, st, (const float*)mid, (long long)pix_stride, im_off,
-                       re_off, n, H, W, L, to_view(*dst), 1.0f / ((float)H * (float)W), pw, vec);
+                       re_off, n, H, W, L, to_view(*dst), 1.0f / ((float)H * (float)W), pw, vec, B);
     FCVSR_LAUNCH_CHECK();
   }
   return 0;

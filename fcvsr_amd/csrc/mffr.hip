@@ -93,6 +93,86 @@ struct DivEnhApplyNextF {
   }
 };
 
+// The same step with 16-byte accesses (C % 4 == 0): thread = (pixel sub-lane, 4-channel group), kRedPix pixels per block,
+// fixed summation order (per thread over its pixels, then over the sub-lanes) - deterministic like reduce_stage1.
+__global__ __launch_bounds__(kRedThreads) void divenh_apply_next_v4_kernel(DivEnhApplyNextF e, int B, float* partial) {
+  __shared__ float4 sm[2][kRedThreads];
+  const int C = e.ex.C, Cq = C >> 2;
+  const long long npix = e.ex.HW;
+  const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+  const int R = kRedThreads / Cq;
+  const int sub = threadIdx.x / Cq, cq = threadIdx.x % Cq;
+  float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
+  if (sub < R) {
+    const int c = cq * 4;
+    const float4 av = *reinterpret_cast<const float4*>(e.ex.a + c), bv = *reinterpret_cast<const float4*>(e.ex.b + c);
+    const float aa[4] = {0.2f * av.x, 0.2f * av.y, 0.2f * av.z, 0.2f * av.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+    float g1v[4], g2v[4] = {0.f, 0.f, 0.f, 0.f}, mean[4] = {0.f, 0.f, 0.f, 0.f}, an[4] = {0.f, 0.f, 0.f, 0.f}, bn[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      g1v[k] = e.g1[b * C + c + k];
+      if (!e.ex.first) g2v[k] = e.g2[b * C + c + k];
+      if (e.ex.first) mean[k] = e.ex.mean_sum[b * C + c + k] * e.ex.inv_hw;
+      if (e.next_kind == 0) { an[k] = 0.2f * e.a_next[c + k]; bn[k] = e.b_next[c + k]; }
+    }
+    const long long p0 = (long long)blk * kRedPix;
+    const long long p1 = (p0 + kRedPix < npix) ? p0 + kRedPix : npix;
+    for (long long p = p0 + sub; p < p1; p += R) {
+      const long long i = ((long long)b * npix + p) * C + c;
+      const float4 f4 = *reinterpret_cast<const float4*>(e.ex.f + i);
+      float4 sf4 = make_float4(0.f, 0.f, 0.f, 0.f), so4 = sf4, fn4 = sf4;
+      if (!e.ex.first) { sf4 = *reinterpret_cast<const float4*>(e.s_f + i); so4 = *reinterpret_cast<const float4*>(e.s_o + i); }
+      if (e.next_kind == 0) fn4 = *reinterpret_cast<const float4*>(e.f_next + i);
+      const float fv[4] = {f4.x, f4.y, f4.z, f4.w}, sf[4] = {sf4.x, sf4.y, sf4.z, sf4.w}, so[4] = {so4.x, so4.y, so4.z, so4.w};
+      const float fn[4] = {fn4.x, fn4.y, fn4.z, fn4.w};
+      float nf[4], no[4], o1[4], o2[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float e1, e2;                                   // exactly DivEnhExprF::eval
+        if (e.ex.first) {
+          const float t = fv[k] - mean[k];
+          e1 = aa[k] * t * fv[k] + bb[k] * fv[k];
+          e2 = 0.f;
+        } else {
+          const float t = fv[k] - sf[k] + 0.2f * so[k];
+          e1 = aa[k] * t * fv[k] + bb[k] * fv[k];
+          e2 = aa[k] * so[k] * fv[k] + bb[k] * fv[k];
+        }
+        float o = e1 * g1v[k];
+        if (!e.ex.first) o += e2 * g2v[k];
+        if (e.ex.first) { nf[k] = fv[k]; no[k] = o; }
+        else { nf[k] = sf[k] + fv[k]; no[k] = so[k] + o; }
+        if (e.next_kind == 0) {
+          const float t = fn[k] - nf[k] + 0.2f * no[k];
+          o1[k] = an[k] * t * fn[k] + bn[k] * fn[k];
+          o2[k] = an[k] * no[k] * fn[k] + bn[k] * fn[k];
+        } else {
+          o1[k] = no[k];
+          o2[k] = 0.f;
+        }
+      }
+      *reinterpret_cast<float4*>(e.s_f + i) = make_float4(nf[0], nf[1], nf[2], nf[3]);
+      *reinterpret_cast<float4*>(e.s_o + i) = make_float4(no[0], no[1], no[2], no[3]);
+      a1.x += o1[0]; a1.y += o1[1]; a1.z += o1[2]; a1.w += o1[3];
+      a2.x += o2[0]; a2.y += o2[1]; a2.z += o2[2]; a2.w += o2[3];
+    }
+  }
+  sm[0][threadIdx.x] = a1;
+  sm[1][threadIdx.x] = a2;
+  __syncthreads();
+  if (threadIdx.x < Cq) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int r = 0; r < R; ++r) {
+        const float4 v = sm[k][r * Cq + threadIdx.x];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+      *reinterpret_cast<float4*>(partial + (((long long)k * B + b) * nblk + blk) * C + threadIdx.x * 4) = t;
+    }
+  }
+}
+
 template <int XD>
 __device__ __forceinline__ float4 ld_x4(const void* base, long long quad) {
   if (XD == FCVSR_F32) return reinterpret_cast<const float4*>(base)[quad];
@@ -171,7 +251,11 @@ extern "C" int fcvsr_divenh_apply_next(int first, const float* f, float* s_f, fl
   const int nblk = red_blocks(HW);
   FCVSR_CHECK_ARG(scratch_elems >= 2ll * B * nblk * C, "scratch too small");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL((reduce_stage1<2, DivEnhApplyNextF>), dim3(nblk, B), dim3(kRedThreads), 0, st, ex, B, HW, C, scratch);
+  const bool v4 = C % 4 == 0 && kRedThreads % (C / 4) == 0 && ((uintptr_t)f % 16) == 0 && ((uintptr_t)s_f % 16) == 0 &&
+                  ((uintptr_t)s_o % 16) == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 &&
+                  ((uintptr_t)scratch % 16) == 0 && (f_next == nullptr || ((uintptr_t)f_next % 16) == 0);
+  if (v4) hipLaunchKernelGGL(divenh_apply_next_v4_kernel, dim3(nblk, B), dim3(kRedThreads), 0, st, ex, B, scratch);
+  else hipLaunchKernelGGL((reduce_stage1<2, DivEnhApplyNextF>), dim3(nblk, B), dim3(kRedThreads), 0, st, ex, B, HW, C, scratch);
   FCVSR_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_stage2, dim3(2 * B), dim3(kRedThreads), 0, st, (const float*)scratch, 2 * B, nblk, C, sums);
   FCVSR_LAUNCH_CHECK();

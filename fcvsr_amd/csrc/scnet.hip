@@ -234,6 +234,7 @@ __global__ void gc_stage2_levels_kernel(GcFinishArgs a, int C, const float* w1, 
   float* hid = sm + C;
   float* scale = sm + 2 * C;
   __shared__ float red[256];
+  __shared__ __align__(16) float red4_s[4 * 256];
   const int b = blockIdx.x, nblk = L.nparts;
   const float* pb = L.part + (long long)b * nblk * (C + 2);
   float gm = -INFINITY;
@@ -260,6 +261,31 @@ __global__ void gc_stage2_levels_kernel(GcFinishArgs a, int C, const float* w1, 
   }
   const float denom_s = red[0];
   __syncthreads();
+  if (C % 4 == 0 && blockDim.x % (C / 4) == 0 && (C + 2) % 2 == 0) {
+    // ctx[c]: thread = (sub-lane, 4-channel group): 256 / (C/4) partial sums per channel over the tiles with 8-byte loads
+    // (rows are C+2 floats long, so a 4-channel group is 8-byte aligned), then a fixed-order combine
+    const int Cq = C / 4, R = blockDim.x / Cq;
+    const int sub = threadIdx.x / Cq, cq = threadIdx.x % Cq;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = sub; k < nblk; k += R) {
+      const float2* pr = reinterpret_cast<const float2*>(pb + (long long)k * (C + 2) + cq * 4);
+      const float2 lo = pr[0], hi = pr[1];
+      const float sc = scale[k];
+      acc.x = fmaf(lo.x, sc, acc.x); acc.y = fmaf(lo.y, sc, acc.y); acc.z = fmaf(hi.x, sc, acc.z); acc.w = fmaf(hi.y, sc, acc.w);
+    }
+    float4* red4 = reinterpret_cast<float4*>(red4_s);
+    red4[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < Cq) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = 0; q < R; ++q) {
+        const float4 v = red4[q * Cq + threadIdx.x];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+      ctx[threadIdx.x * 4] = t.x / denom_s; ctx[threadIdx.x * 4 + 1] = t.y / denom_s;
+      ctx[threadIdx.x * 4 + 2] = t.z / denom_s; ctx[threadIdx.x * 4 + 3] = t.w / denom_s;
+    }
+  } else
   {
     const int R = blockDim.x / C;
     const int sub = threadIdx.x / C, c = threadIdx.x % C;

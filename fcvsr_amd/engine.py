@@ -300,15 +300,19 @@ class Engine:
 
         # A multi-scale ConvBlk heads -> (real, imag) planes -> irfft2 -> pixel offsets
         ospec = self._new(dev, B, H, Wf, 8 * A)                  # re: [0,4A), im: [4A,8A); channel = (dir*A+i)*2 + j
-        tt = self._new(dev, 2 * B, H, Wf, 4)
         u = self._new(dev, 2 * B, H, Wf, 4)
+        ntile = ((H + 15) // 16) * ((Wf + 15) // 16)
+        partial = self._new(dev, 2 * B * ntile * 4)
         for i in range(A):
             pre = f"MGAA.MConvB.{i}"
-            self._conv(pre + ".conv1", [off4], tt, act=ACT_PRELU, slope_t=par[pre + ".relu.weight"], direct=True)
-            self._conv(pre + ".conv2", [tt], u, direct=True)
-            gate = self._ca_gate(self._channel_sum(u), 1.0 / (H * Wf), pre + ".CA", 2 * B, 4)
-            check(L.fcvsr_convblk_tail(u.data_ptr(), gate.data_ptr(), sim.data_ptr(), B, 2, H, Wf, ospec.data_ptr(),
-                                       8 * A, 0, 4 * A, A, i, st), "fcvsr_convblk_tail")
+            # conv1 + PReLU + conv2 + channel sums in one launch, CALayer gate + (. * sim) + plane split in a second
+            w1 = self._weights(pre + ".conv1", "direct")[0]
+            w2 = self._weights(pre + ".conv2", "direct")[0]
+            check(L.fcvsr_convblk(off4.data_ptr(), w1.data_ptr(), w2.data_ptr(), par[pre + ".relu.weight"].data_ptr(),
+                                  par[pre + ".conv1.weight"].shape[-1], par[pre + ".CA.conv_du.0.weight"].data_ptr(),
+                                  par[pre + ".CA.conv_du.2.weight"].data_ptr(), sim.data_ptr(), B, 2, H, Wf, u.data_ptr(),
+                                  partial.data_ptr(), partial.numel(), ospec.data_ptr(), 8 * A, 0, 4 * A, A, i, st),
+                  "fcvsr_convblk")
         offsets = self._new(dev, B, H, W, 4 * A)
         ov = view(offsets)
         check(L.fcvsr_irfft2(ospec.data_ptr(), 8 * A, 4 * A, 0, B, H, W, 4 * A, None, None, C.byref(ov), st),

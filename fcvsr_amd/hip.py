@@ -76,6 +76,7 @@ SIGNATURES = {
     "fcvsr_channel_sum": [_PV, _I, _I, _I, _VP, _VP, _I64, _VP],
     "fcvsr_ca_gate": [_VP, _F, _VP, _VP, _I, _I, _I, _VP, _VP],
     "fcvsr_convblk_tail": [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _I64, _I, _I, _I, _I, _VP],
+    "fcvsr_convblk": [_VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _I64, _VP, _I64, _I, _I, _I, _I, _VP],
     "fcvsr_warp": [_PV, _PV, _I, _I, _I, _PV, _VP],
     "fcvsr_sac_v": [_PV, _PV, _I, _I, _I, _PV, _VP],
     "fcvsr_sac_h": [_PV, _PV, _PV, _F, _I, _I, _I, _PV, _VP],

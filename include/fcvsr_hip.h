@@ -121,6 +121,15 @@ int fcvsr_ca_gate(const float* sum, float inv_hw, const float* w1, const float* 
  *   writes re (o[0:2]) to spec channel re_off + 2*g + j and im (o[2:4]) to im_off + 2*g + j, g = dir*A + i */
 int fcvsr_convblk_tail(const float* u, const float* gate, const float* sim, int B, int ndir, int H, int Wf,
                        float* spec, int64_t pix_stride, int re_off, int im_off, int g_stride, int g0, void* stream);
+/* One whole ConvBlk head (:344-357 applied at :1494-1498) in two launches:
+ *   u = conv2(PReLU(conv1(x)))  (k x k, 4 -> 4, no bias; w1 / w2 in the direct packing [k*k][4][16] f32, one PReLU slope),
+ *   then what fcvsr_convblk_tail does, with the CALayer gate (4 -> 4 -> 4, ca_w1 / ca_w2 row-major, no bias) evaluated from
+ *   per-tile channel sums inside the second launch.  x, u_scratch: (ndir*B, H, Wf, 4) f32 dense; sim: (B, H, Wf, 4);
+ *   partial_scratch: 4 * ndir*B * ceil(H/16)*ceil(Wf/16) floats. */
+int fcvsr_convblk(const float* x, const float* w1, const float* w2, const float* prelu_slope, int ksize, const float* ca_w1,
+                  const float* ca_w2, const float* sim, int B, int ndir, int H, int Wf, float* u_scratch,
+                  float* partial_scratch, int64_t partial_elems, float* spec, int64_t pix_stride, int re_off, int im_off,
+                  int g_stride, int g0, void* stream);
 /* flow_warp (:1188-1227): bilinear, zeros padding, sample at (x+off[0], y+off[1]) */
 int fcvsr_warp(const fcvsr_view* src, const fcvsr_view* off, int B, int H, int W, const fcvsr_view* dst, void* stream);
 /* SAC (:1253-1276) vertical pass: v = sum_t s[clamp(y+t-1)] * k1[c*3+t] */

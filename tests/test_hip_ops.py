@@ -412,3 +412,43 @@ def test_freq_mlp3_matches_three_1x1_launches():
                                 hip.stream_ptr()), "freq_mlp3")
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("k", [1, 3, 5, 7])
+def test_convblk_fused_head_matches_separate_launches(k):
+    """fcvsr_convblk (conv1 + PReLU + conv2 + channel sums | gate + tail) against the six stand-alone launches it replaces."""
+    from fcvsr_amd import hip
+    L = hip.lib()
+    st = hip.stream_ptr()
+    B, H, Wf, A, i = 2, 21, 19, 3, 1                         # partial 16x16 tiles in both directions
+    x = nhwc(_rand(2 * B, 4, H, Wf, seed=200 + k))
+    sim = nhwc(_rand(B, 4, H, Wf, seed=201))
+    w1 = _rand(4, 4, k, k, seed=202).cuda() / (2.0 * k)
+    w2 = _rand(4, 4, k, k, seed=203).cuda() / (2.0 * k)
+    slope = torch.tensor([0.25], device="cuda")
+    cw1, cw2 = _rand(4, 4, seed=204).cuda(), _rand(4, 4, seed=205).cuda()
+    p1, p2 = hip.pack_conv_weight(w1), hip.pack_conv_weight(w2)
+    # separate launches
+    tt, u = torch.empty_like(x), torch.empty_like(x)
+    hip.conv2d([x], p1, k, 4, tt, act=hip.ACT_PRELU, slope_t=slope)
+    hip.conv2d([tt], p2, k, 4, u)
+    nblk = (H * Wf + 255) // 256
+    sums, scratch = torch.empty(2 * B, 4, device="cuda"), torch.empty(2 * B * nblk * 4, device="cuda")
+    uv = hip.view(u)
+    hip.check(L.fcvsr_channel_sum(C.byref(uv), 2 * B, H, Wf, sums.data_ptr(), scratch.data_ptr(), scratch.numel(), st), "sum")
+    gate = torch.empty(2 * B, 4, device="cuda")
+    hip.check(L.fcvsr_ca_gate(sums.data_ptr(), 1.0 / (H * Wf), cw1.data_ptr(), cw2.data_ptr(), 2 * B, 4, 4, gate.data_ptr(), st), "gate")
+    ref = torch.zeros(B, H, Wf, 8 * A, device="cuda")
+    hip.check(L.fcvsr_convblk_tail(u.data_ptr(), gate.data_ptr(), sim.data_ptr(), B, 2, H, Wf, ref.data_ptr(), 8 * A, 0, 4 * A, A, i,
+                                   st), "tail")
+    # fused
+    out = torch.zeros_like(ref)
+    u2 = torch.empty_like(x)
+    ntile = ((H + 15) // 16) * ((Wf + 15) // 16)
+    part = torch.empty(2 * B * ntile * 4, device="cuda")
+    hip.check(L.fcvsr_convblk(x.data_ptr(), p1.data_ptr(), p2.data_ptr(), slope.data_ptr(), k, cw1.data_ptr(), cw2.data_ptr(),
+                              sim.data_ptr(), B, 2, H, Wf, u2.data_ptr(), part.data_ptr(), part.numel(), out.data_ptr(), 8 * A, 0,
+                              4 * A, A, i, st), "convblk")
+    torch.cuda.synchronize()
+    assert float((u2 - u).abs().max()) < 1e-5
+    assert float((out - ref).abs().max()) < 1e-5

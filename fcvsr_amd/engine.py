@@ -127,6 +127,17 @@ class Engine:
             self._packed[key] = (pk, b, w.shape[0], w.shape[-1])
         return self._packed[key]
 
+    def _feat_weights(self):
+        """feat_extract.0 as a [cout][64] f16 matrix, column k = tap*Cin + c (the im2col order of fcvsr_feat_extract)."""
+        key = ("feat_extract.0", "im2col")
+        if key not in self._packed:
+            w = self._par["feat_extract.0.weight"].detach()      # (cout, cin, 3, 3)
+            b = self._par.get("feat_extract.0.bias")
+            mat = torch.zeros(w.shape[0], 64, device=w.device, dtype=torch.float32)
+            mat[:, :9 * w.shape[1]] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+            self._packed[key] = (mat.to(torch.float16).contiguous(), b.detach().contiguous() if b is not None else None)
+        return self._packed[key]
+
     def _tap_weights(self, name, dt):
         """A 3x3 layer with one output channel as a [16][cin] table in dtype dt: row = tap ky*3+kx, rows 9..15 zero (the
         B operand of the 'taps are output columns' GEMM of the fused tail kernel)."""
@@ -613,7 +624,7 @@ class Engine:
             # hipGraph mode: the ~650 launches of one forward are captured once per (shape, precision, streams, weights
             # version) and replayed, which removes the host launch cost (~9 us per ctypes launch) from the critical path.
             key = (tuple(x.shape), self.precision, ns, str(dev), self._pack_epoch,
-                   tuple(bool(getattr(m, f, True)) for f in ("trunk16", "fold_f1", "fuse_tail", "pool_first", "fuse_freq_mlp")))
+                   tuple(bool(getattr(m, f, True)) for f in ("trunk16", "fold_f1", "fuse_tail", "pool_first", "fuse_freq_mlp", "fast_feat")))
             ent = self._graphs.get(key)
             if ent is None:
                 sx = x.clone()
@@ -665,9 +676,25 @@ class Engine:
         adt = self._tdt()
         f13 = self._new(dev, 2 * B, H, W, 3 * n, dtype=adt)      # [f1 of every clip | f3 of every clip]
         f2 = self._new(dev, B, H, W, n, dtype=adt)
-        self._conv("feat_extract.0", [xin], f13[:B], force_f16=True, rows=(0, 3 * n))
-        self._conv("feat_extract.0", [xin], f13[B:], force_f16=True, rows=(4 * n, 7 * n))
-        self._conv("feat_extract.0", [xin], f2, force_f16=True, rows=(3 * n, 4 * n))
+        cin = T * Cimg
+        if adt != torch.float32 and cin == 7 and n == 64 and getattr(m, "fast_feat", True):
+            # the whole 3x3 patch fits one K = 64 GEMM step: dedicated kernel, the 7 output blocks go straight to f1 | f2 | f3
+            wf, bf = self._feat_weights()
+            xv = view(xin)
+            nb = 7 * n // 64
+            P = C.c_void_p * nb
+            es = f13.element_size()
+            f3_ptr = f13.data_ptr() + B * H * W * 3 * n * es
+            ptrs = [f13.data_ptr()] * 3 + [f2.data_ptr()] + [f3_ptr] * 3
+            strides = [3 * n] * 3 + [n] + [3 * n] * 3
+            choff = [0, 64, 128, 0, 0, 64, 128]
+            check(L.fcvsr_feat_extract(C.byref(xv), B, H, W, wf.data_ptr(), ptr(bf), nb, P(*ptrs),
+                                       (C.c_int64 * nb)(*strides), (C.c_int32 * nb)(*choff), self._code(adt), st),
+                  "fcvsr_feat_extract")
+        else:
+            self._conv("feat_extract.0", [xin], f13[:B], force_f16=True, rows=(0, 3 * n))
+            self._conv("feat_extract.0", [xin], f13[B:], force_f16=True, rows=(4 * n, 7 * n))
+            self._conv("feat_extract.0", [xin], f2, force_f16=True, rows=(3 * n, 4 * n))
         if self.taps is not None:
             self._tap("feat", torch.cat([f13[:B].float(), f2.float(), f13[B:].float()], dim=3))
         a13 = self._mgaa(f13[..., :n], f13[..., n:2 * n], f13[..., 2 * n:], "13")

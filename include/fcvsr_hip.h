@@ -103,6 +103,14 @@ int fcvsr_rfft2(const fcvsr_view* src, int B, int H, int W, int n,
 int fcvsr_irfft2(const float* spec, int64_t pix_stride, int im_off, int re_off, int B, int H, int W, int n,
                  const float* mask, float* work, const fcvsr_view* dst, void* stream);
 
+/* feat_extract (:2589, Conv2d(Cin, n_blk*64, 3, 1, 1), Cin = 7: 9*Cin <= 64) as one K = 64 GEMM step per output tile.
+ * x: (B,H,W,Cin) f32 view of the planar frames; w: [n_blk*64][64] f16, column k = tap*Cin + c (zero beyond 9*Cin);
+ * output block i (64 channels) goes to dst[i] (16-bit, dtype dst_dtype) at channel offset dst_ch_off[i], pixels
+ * dst_pix_stride[i] elements apart (flat pixel index (b*H + y)*W + x). */
+int fcvsr_feat_extract(const fcvsr_view* x, int B, int H, int W, const void* w, const float* bias, int n_blk,
+                       void* const* dst, const int64_t* dst_pix_stride, const int32_t* dst_ch_off, int dst_dtype,
+                       void* stream);
+
 /* ---- MGAAbk pieces (CVSR_freq.py:1365-1547) ---------------------------------------------------------------- */
 /* CorrBlock lookup on the integer grid (:1279-1337): x1f,x2f NHWC (B,H,Wf,C) with pixel stride
  * pix_stride (floats); dst (B,H,x_count,>=81); channels beyond (2r+1)^2 are zero-filled.  Only the first x_count

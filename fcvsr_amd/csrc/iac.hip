@@ -386,27 +386,48 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
   // ---- software pipeline over the (up to two) directions: every load of direction 1 that does not depend on LDS is in
   // flight while direction 0 runs its LDS phases -------------------------------------------------------------------------
   constexpr int NP = (kIHY * kIHX + 31) / 32;
-  int cgx[NP], cgy[NP];                                // clamped coordinates of the lane's halo pixels (direction-independent)
-#pragma unroll
-  for (int it = 0; it < NP; ++it) {
-    int hp = it * 32 + ps;
+  static_assert(NP * 8 * ND <= 64, "one sampling slot per lane");
+  // ---- sampling set-up, one (direction, iteration, pixel) slot per LANE.  A wave covers 8 halo pixels per iteration and
+  // the 8 lanes of a pixel need the same offsets / tap addresses / tap weights: instead of every lane redoing the ~75
+  // instructions for each of its NP x ND pixels, lane l computes slot (dir, it, pixel) = (l >> 5, (l >> 3) & 3, l & 7) once
+  // and the values are handed out with wave shuffles below (no LDS round trip, no barrier).
+  const int wv = wave;
+  int my_eo[4];
+  float my_w[4];
+  {
+    const int sdir = (lane >> 5) < ND ? (lane >> 5) : 0, sit = (lane >> 3) & 3, spl = lane & 7;
+    int hp = sit * 32 + wv * 8 + spl;
     hp = hp < kIHY * kIHX ? hp : kIHY * kIHX - 1;
     const int hy = hp / kIHX, hx = hp - hy * kIHX;
     int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-    cgy[it] = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
-    cgx[it] = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
+    gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
+    gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
+    const View off = a.d[sdir].off, prev = a.d[sdir].prev;
+    const float* op = off.p + (long long)b * off.sb + (long long)gy * off.sy + (long long)gx * off.sx;
+    const float fx = (float)gx + op[0];
+    const float fy = (float)gy + op[off.sc];
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float wx1 = fx - x0f, wy1 = fy - y0f;
+    const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const bool sane = (fx > -2.f) && (fx < (float)W + 1.f) && (fy > -2.f) && (fy < (float)H + 1.f);
+    const int x0 = sane ? (int)x0f : -4, y0 = sane ? (int)y0f : -4;
+    const int psy = (int)prev.sy, psx = (int)prev.sx;   // 32-bit offsets inside one image (host checks H*sy < 2^31)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int xi = x0 + dx, yi = y0 + dy;
+        const bool in = xi >= 0 && xi < W && yi >= 0 && yi < H;
+        const int xc = xi < 0 ? 0 : (xi > W - 1 ? W - 1 : xi), yc = yi < 0 ? 0 : (yi > H - 1 ? H - 1 : yi);
+        my_w[dy * 2 + dx] = in ? (dy ? wy1 : wy0) * (dx ? wx1 : wx0) : 0.f;   // 0 outside the image = zero padding
+        my_eo[dy * 2 + dx] = yc * psy + xc * psx;
+      }
+    }
   }
-  float ox[ND][NP], oy[ND][NP];
   Pack8<ADT> fpk[ND][2];
 #pragma unroll
   for (int dir = 0; dir < ND; ++dir) {
-    const View off = a.d[dir].off, fin = a.d[dir].fin;
-#pragma unroll
-    for (int it = 0; it < NP; ++it) {
-      const float* op = off.p + (long long)b * off.sb + (long long)cgy[it] * off.sy + (long long)cgx[it] * off.sx;
-      ox[dir][it] = op[0];
-      oy[dir][it] = op[off.sc];
-    }
+    const View fin = a.d[dir].fin;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int p = j * 32 + ps;
@@ -419,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
   if (FK) predictor_gemm();                            // operands requested above, together with the offsets
 
   // phase 1a: the 4 x NP bilinear taps of a direction (unconditional: out-of-image taps read a clamped address with
-  // weight 0, which is what the zero padding of flow_warp amounts to)
+  // weight 0); addresses and weights come from the slot owner's registers
   Pack8<ADT> tap[ND][NP][4];
   float tw[ND][NP][4];
   auto issue_taps = [&](const int dir) {
@@ -427,27 +448,13 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
     const long long pp = (long long)b * prev.sb + c0;
     const float* pb = ADT == FCVSR_F32 ? prev.p + pp
                                        : reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(prev.p) + pp);
-    const int psy = (int)prev.sy, psx = (int)prev.sx;   // 32-bit offsets inside one image (host checks H*sy < 2^31)
 #pragma unroll
     for (int it = 0; it < NP; ++it) {
-      const float fx = (float)cgx[it] + ox[dir][it];
-      const float fy = (float)cgy[it] + oy[dir][it];
-      const float x0f = floorf(fx), y0f = floorf(fy);
-      const float wx1 = fx - x0f, wy1 = fy - y0f;
-      const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-      const bool sane = (fx > -2.f) && (fx < (float)W + 1.f) && (fy > -2.f) && (fy < (float)H + 1.f);
-      const int x0 = sane ? (int)x0f : -4, y0 = sane ? (int)y0f : -4;
+      const int src = dir * 32 + it * 8 + (lane >> 3);  // the lane that owns (dir, it, this lane's pixel)
 #pragma unroll
-      for (int dy = 0; dy < 2; ++dy) {
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-          const int xi = x0 + dx, yi = y0 + dy;
-          const bool in = xi >= 0 && xi < W && yi >= 0 && yi < H;
-          const int xc = xi < 0 ? 0 : (xi > W - 1 ? W - 1 : xi), yc = yi < 0 ? 0 : (yi > H - 1 ? H - 1 : yi);
-          tw[dir][it][dy * 2 + dx] = in ? (dy ? wy1 : wy0) * (dx ? wx1 : wx0) : 0.f;
-          const int eo = yc * psy + xc * psx;
-          tap[dir][it][dy * 2 + dx] = ld_p8<ADT>(pb, eo);
-        }
+      for (int q = 0; q < 4; ++q) {
+        tw[dir][it][q] = __shfl(my_w[q], src);
+        tap[dir][it][q] = ld_p8<ADT>(pb, __shfl(my_eo[q], src));
       }
     }
   };

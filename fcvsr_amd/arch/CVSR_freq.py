@@ -205,6 +205,8 @@ class _GShiftBase(nn.Module):
         self.fuse_freq_mlp = os.environ.get("FCVSR_FUSE_FREQ_MLP", "1") == "1"
         # 16-bit modes, 9*Cin <= 64 (the Y models): feat_extract as a single-K-step GEMM kernel
         self.fast_feat = os.environ.get("FCVSR_FAST_FEAT", "1") == "1"
+        # 16-bit modes, n_features == 64: convcrt and (away from the CorrBlock strip) convcorr as one launch each
+        self.fuse_freq_head = os.environ.get("FCVSR_FUSE_FREQ_HEAD", "1") == "1"
         # capture the launch sequence of a forward in a hipGraph (per input shape) and replay it
         self.use_graph = os.environ.get("FCVSR_GRAPH", "0") == "1"
 

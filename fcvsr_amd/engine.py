@@ -274,27 +274,46 @@ class Engine:
             self._convg("MGAA.convfuse.2", [dict(srcs=[t0], dst=t1)], act=ACT_RELU, freq=True)
             self._convg("MGAA.convfuse.4", [dict(srcs=[t1[d * B:(d + 1) * B]], dst=off[d * B:(d + 1) * B], res=[xa, x2f])
                                             for d, xa in dirs], res_scale=[1.0, -1.0], freq=True)
-        s0 = self._new(dev, B, H, Wf, n, dtype=fdt)
         sim = self._new(dev, B, H, Wf, 4)
-        self._conv("MGAA.convcrt.0", [x2f], s0, act=ACT_RELU, freq=True)
-        self._conv("MGAA.convcrt.2", [s0], sim, freq=True)
-
-        c0 = self._new(dev, 2 * B, H, Wf, n, dtype=fdt)
-        c1 = self._new(dev, 2 * B, H, Wf, n, dtype=fdt)
         off4 = self._new(dev, 2 * B, H, Wf, 4)
+        fuse_head = fuse_mlp and getattr(m, "fuse_freq_head", True)
+        if fuse_head:
+            # convcrt (128 -> 64 -> 4 on the centre spectrum) as one launch
+            check(L.fcvsr_freq_head(x2f.data_ptr(), hip.F32, 6 * n, B * H * Wf,
+                                    self._weights("MGAA.convcrt.0", torch.bfloat16)[0].data_ptr(), None,
+                                    self._weights("MGAA.convcrt.2", torch.bfloat16)[0].data_ptr(), sim.data_ptr(), st),
+                  "fcvsr_freq_head(convcrt)")
+        else:
+            s0 = self._new(dev, B, H, Wf, n, dtype=fdt)
+            self._conv("MGAA.convcrt.0", [x2f], s0, act=ACT_RELU, freq=True)
+            self._conv("MGAA.convcrt.2", [s0], sim, freq=True)
+
         if fdt == torch.float32:
+            c0 = self._new(dev, 2 * B, H, Wf, n, dtype=fdt)
+            c1 = self._new(dev, 2 * B, H, Wf, n, dtype=fdt)
             corr = self._new(dev, B, H, Wf, 84)                  # 81 live channels + 3 zero pad (16-byte pixels)
             cv = view(corr)
             check(L.fcvsr_corr_lookup(x1f.data_ptr(), x2f.data_ptr(), 6 * n, B, H, Wf, 2 * n, 4, Wf, C.byref(cv), st),
                   "fcvsr_corr_lookup")
             for d in range(2):
                 self._conv("MGAA.convcorr.0", [off[d * B:(d + 1) * B], corr], c0[d * B:(d + 1) * B], act=ACT_RELU, freq=True)
+            self._conv("MGAA.convcorr.2", [c0], c1, act=ACT_RELU, freq=True)
+            self._conv("MGAA.convcorr.4", [c1], off4, freq=True)
         else:
             # The CorrBlock lookup is identically zero beyond column radius+1 = 5 (it samples a 2-pixel-wide image,
             # CVSR_freq.py:1318-1337), so its 81 input channels contribute exact zeros to convcorr.0 everywhere else:
-            # one launch over both directions on the offset spectra alone, then the narrow strip x < 8 is recomputed with
-            # the lookup channels and pasted over - the same sums as the full concat (zeros add nothing to an f32 chain).
-            self._conv("MGAA.convcorr.0", [off], c0, act=ACT_RELU, freq=True, cols=(0, 2 * n))
+            # the stack runs over both directions on the offset spectra alone, then the narrow strip x < 8 is recomputed
+            # with the lookup channels and pasted over - the same sums as the full concat (zeros add nothing to an f32 chain).
+            if fuse_head:
+                check(L.fcvsr_freq_head(off.data_ptr(), hip.BF16, 2 * n, 2 * B * H * Wf,
+                                        self._weights("MGAA.convcorr.0", torch.bfloat16, cols=(0, 2 * n))[0].data_ptr(),
+                                        self._weights("MGAA.convcorr.2", torch.bfloat16)[0].data_ptr(),
+                                        self._weights("MGAA.convcorr.4", torch.bfloat16)[0].data_ptr(), off4.data_ptr(), st),
+                      "fcvsr_freq_head(convcorr)")
+            else:
+                c0 = self._new(dev, 2 * B, H, Wf, n, dtype=fdt)
+                c1 = self._new(dev, 2 * B, H, Wf, n, dtype=fdt)
+                self._conv("MGAA.convcorr.0", [off], c0, act=ACT_RELU, freq=True, cols=(0, 2 * n))
             xs = min(Wf, 8)
             corr = self._new(dev, B, H, xs, 84)
             cv = view(corr)
@@ -305,9 +324,16 @@ class Engine:
             for d in range(2):
                 self._conv("MGAA.convcorr.0", [off_s[d * B:(d + 1) * B], corr], c0_s[d * B:(d + 1) * B], act=ACT_RELU,
                            freq=True)
-            c0[:, :, :xs].copy_(c0_s)
-        self._conv("MGAA.convcorr.2", [c0], c1, act=ACT_RELU, freq=True)
-        self._conv("MGAA.convcorr.4", [c1], off4, freq=True)
+            if fuse_head:
+                c1_s = self._new(dev, 2 * B, H, xs, n, dtype=fdt)
+                off4_s = self._new(dev, 2 * B, H, xs, 4)
+                self._conv("MGAA.convcorr.2", [c0_s], c1_s, act=ACT_RELU, freq=True)
+                self._conv("MGAA.convcorr.4", [c1_s], off4_s, freq=True)
+                off4[:, :, :xs].copy_(off4_s)
+            else:
+                c0[:, :, :xs].copy_(c0_s)
+                self._conv("MGAA.convcorr.2", [c0], c1, act=ACT_RELU, freq=True)
+                self._conv("MGAA.convcorr.4", [c1], off4, freq=True)
 
         # A multi-scale ConvBlk heads -> (real, imag) planes -> irfft2 -> pixel offsets
         ospec = self._new(dev, B, H, Wf, 8 * A)                  # re: [0,4A), im: [4A,8A); channel = (dir*A+i)*2 + j
@@ -624,7 +650,7 @@ class Engine:
             # hipGraph mode: the ~650 launches of one forward are captured once per (shape, precision, streams, weights
             # version) and replayed, which removes the host launch cost (~9 us per ctypes launch) from the critical path.
             key = (tuple(x.shape), self.precision, ns, str(dev), self._pack_epoch,
-                   tuple(bool(getattr(m, f, True)) for f in ("trunk16", "fold_f1", "fuse_tail", "pool_first", "fuse_freq_mlp", "fast_feat")))
+                   tuple(bool(getattr(m, f, True)) for f in ("trunk16", "fold_f1", "fuse_tail", "pool_first", "fuse_freq_mlp", "fuse_freq_head", "fast_feat")))
             ent = self._graphs.get(key)
             if ent is None:
                 sx = x.clone()
@@ -648,6 +674,8 @@ class Engine:
         # Clips are independent: run sub-batches on separate HIP streams.  Every kernel of the path has serial phases
         # (stage -> MFMA -> store); with several forwards in flight the hardware interleaves workgroups of different
         # kernels, so HBM-bound and MFMA-bound phases of different sub-batches overlap and launch tails are filled.
+        # Opt-in (model.streams > 1, default 1): worth +3.7 % at B=16, but with kernels of several HW queues sharing the CUs
+        # graph replays were not bit-reproducible on the measured stack (DESIGN.md "Multi-stream replays") - one stream is.
         out = self._new(dev, B, Cimg, 4 * H, 4 * W)
         cur = torch.cuda.current_stream(dev)
         while len(self._streams) < ns:

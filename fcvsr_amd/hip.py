@@ -82,6 +82,7 @@ SIGNATURES = {
     "fcvsr_sac_h": [_PV, _PV, _PV, _F, _I, _I, _I, _PV, _VP],
     "fcvsr_iac_step": [_PV, _PV, _PV, _PV, _F, _I, _I, _I, _PV, _VP],
     "fcvsr_feat_extract": [_PV, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _VP, _I, _VP],
+    "fcvsr_freq_head": [_VP, _I, _I64, _I64, _VP, _VP, _VP, _VP, _VP],
     "fcvsr_freq_mlp3": [_VP, _VP, _I, _I64, _I64, _VP, _VP, _VP, _VP, _I64, _VP],
     "fcvsr_iac_step2": [_PV, _PV, _PV, _PV, _F, _I, _I, _I, _PV, _VP],
     "fcvsr_iac_step2_fused": [_PV, _PV, _PV, _VP, _VP, _PV, _F, _I, _I, _I, _PV, _VP],

@@ -171,6 +171,14 @@ int fcvsr_iac_step2_fused(const fcvsr_view* prev, const fcvsr_view* off, const f
 int fcvsr_freq_mlp3(const float* const* xa, const float* const* xb, int n_dirs, int64_t src_pix_stride, int64_t npix,
                     const void* w0, const void* w2, const void* w4, void* const* dst, int64_t dst_pix_stride, void* stream);
 
+/* The narrow 1x1 stacks on the spectrum grid as one launch each: out(npix,4) f32 = W_last . relu([W_mid . relu](W_0 . x)),
+ * x (npix, 128 channels, x_pix_stride elements apart) f32 or bf16, hidden width 64, bf16 operands / f32 accumulate.
+ * w0 [>=64][128], w_mid [>=64][64] or NULL, w_last [>=32][64] (rows 0..3 live) bf16 with cin contiguous (MFMA packing).
+ * convcrt (:1392-1396): w_mid = NULL on the centre spectrum; convcorr (:1379-1385) away from the CorrBlock strip: the
+ * offset spectra with the first 128 input columns of convcorr.0. */
+int fcvsr_freq_head(const void* x, int x_dtype, int64_t x_pix_stride, int64_t npix, const void* w0, const void* w_mid,
+                    const void* w_last, float* out, void* stream);
+
 /* ---- MultiFreq_Refinment pieces (CVSR_freq.py:2104-2133, :2201-2254) ---------------------------------------- */
 /* DivEnh expressions, i==0 (first=1): t=f-mean_f; e1=0.2*a*t*f+b*f.  i>0: t=f-s_f+0.2*s_o; e1 as above;
  * e2=0.2*a*s_o*f+b*f.   mode 0: write per-(b,c) sums of e1,e2 to sums[2][B][C] (two-stage, deterministic);

@@ -452,3 +452,38 @@ def test_convblk_fused_head_matches_separate_launches(k):
     torch.cuda.synchronize()
     assert float((u2 - u).abs().max()) < 1e-5
     assert float((out - ref).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("nhid,src", [(2, "bf16"), (1, "f32")])
+def test_freq_head_matches_separate_1x1_launches(nhid, src):
+    """fcvsr_freq_head (convcorr: 128 -> 64 -> 64 -> 4 on bf16 input; convcrt: 128 -> 64 -> 4 on an f32 spectrum slice)
+    against the stand-alone MFMA 1x1 launches with bf16 hidden tensors."""
+    from fcvsr_amd import hip
+    L = hip.lib()
+    npix_shape = (2, 9, 23)                                 # 414 pixels: partial last workgroup
+    dt = torch.bfloat16
+    if src == "bf16":
+        x = nhwc(_rand(npix_shape[0], 128, *npix_shape[1:], seed=301)).to(dt)
+        xs, sx, code = x, 128, hip.BF16
+    else:
+        spec = nhwc(_rand(npix_shape[0], 384, *npix_shape[1:], seed=302))
+        xs, sx, code = spec[..., 128:256], 384, hip.F32
+    w0 = _rand(64, 128, 1, 1, seed=303).cuda() / 11
+    w1 = _rand(64, 64, 1, 1, seed=304).cuda() / 8
+    wl = _rand(4, 64, 1, 1, seed=305).cuda() / 8
+    p0, p1, pl = (hip.pack_conv_weight_mfma(w, dt) for w in (w0, w1, wl))
+    B, H, Wf = npix_shape
+    t0 = torch.empty(B, H, Wf, 64, device="cuda", dtype=dt)
+    t1 = torch.empty_like(t0)
+    ref = torch.empty(B, H, Wf, 4, device="cuda")
+    hip.conv2d_mfma([dict(srcs=[xs], dst=t0)], p0, 1, 64, hip.BF16, act=hip.ACT_RELU)
+    last = t0
+    if nhid == 2:
+        hip.conv2d_mfma([dict(srcs=[t0], dst=t1)], p1, 1, 64, hip.BF16, act=hip.ACT_RELU)
+        last = t1
+    hip.conv2d_mfma([dict(srcs=[last], dst=ref)], pl, 1, 4, hip.BF16)
+    out = torch.zeros_like(ref)
+    hip.check(L.fcvsr_freq_head(xs.data_ptr(), code, sx, B * H * Wf, p0.data_ptr(), p1.data_ptr() if nhid == 2 else None,
+                                pl.data_ptr(), out.data_ptr(), hip.stream_ptr()), "freq_head")
+    torch.cuda.synchronize()
+    assert float((out - ref).abs().max()) <= 1e-6 * float(ref.abs().max())

@@ -12,6 +12,15 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfcvsr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-ffp-contract=off"] + os.environ.get("FCVSR_EXTRA_FLAGS", "").split()
+# Packed-FP32 VALU ops (v_pk_add/mul/fma_f32, formed by the SLP vectoriser) that consume freshly returned LDS data were
+# measured to produce wrong lanes when a workgroup of another HW queue keeps the CU's LDS busy (DESIGN.md section 6,
+# "Multi-stream replays"; scripts/fft_corun.py reproduces it in seconds).  The files listed in SLP_FILES keep the
+# vectoriser (their packed ops are in VALU-bound MFMA epilogues and showed no such failure); everything else is built without.
+SLP_FILES = set(os.environ.get("FCVSR_SLP_FILES", "conv_mfma.hip,conv_ws.hip,iac.hip,tail_fused.hip,freq_mlp.hip,freq_head.hip,feat_extract.hip").split(","))
+
+
+def flags_for(src: str):
+    return FLAGS if os.path.basename(src) in SLP_FILES else FLAGS + ["-fno-slp-vectorize"]
 
 
 def sources():
@@ -24,7 +33,7 @@ def _stamp() -> str:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode())
             h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update((" ".join(FLAGS) + "|" + ",".join(sorted(SLP_FILES))).encode())
     return h.hexdigest()
 
 
@@ -39,7 +48,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in sources():
         obj = os.path.join(LIBDIR, os.path.basename(src) + ".o")
         objs.append(obj)
-        procs.append((src, subprocess.Popen([HIPCC, *FLAGS, "-c", src, "-o", obj], stdout=subprocess.PIPE,
+        procs.append((src, subprocess.Popen([HIPCC, *flags_for(src), "-c", src, "-o", obj], stdout=subprocess.PIPE,
                                             stderr=subprocess.STDOUT)))
     for src, p in procs:
         out = p.communicate()[0].decode()

@@ -674,8 +674,8 @@ class Engine:
         # Clips are independent: run sub-batches on separate HIP streams.  Every kernel of the path has serial phases
         # (stage -> MFMA -> store); with several forwards in flight the hardware interleaves workgroups of different
         # kernels, so HBM-bound and MFMA-bound phases of different sub-batches overlap and launch tails are filled.
-        # Opt-in (model.streams > 1, default 1): worth +3.7 % at B=16, but with kernels of several HW queues sharing the CUs
-        # graph replays were not bit-reproducible on the measured stack (DESIGN.md "Multi-stream replays") - one stream is.
+        # Worth +4-5 % at B=16.  (Kernels of several HW queues then share the CUs: see DESIGN.md "Multi-stream replays" for
+        # the packed-FP32 / LDS hazard this exposed and how the build avoids it.)
         out = self._new(dev, B, Cimg, 4 * H, 4 * W)
         cur = torch.cuda.current_stream(dev)
         while len(self._streams) < ns:

@@ -121,3 +121,21 @@ def test_sliding_window_indices():
     assert window_indices(0, 5, 100, "reflection_circle") == [4, 3, 0, 1, 2]
     assert window_indices(99, 5, 100, "reflection") == [97, 98, 99, 98, 97]
     assert window_indices(99, 5, 100, "reflection_circle") == [97, 98, 99, 96, 95]
+
+
+def test_build_keeps_packed_fp32_out_of_the_lds_kernels(tmp_path):
+    """The packed-FP32 / LDS hazard: every file except the listed ones is compiled without the SLP
+    vectoriser, and the FFT object really contains no v_pk_*_f32 instruction."""
+    import shutil
+    import subprocess
+    from fcvsr_amd import build as B
+    for f in ("fft.hip", "mffr.hip", "scnet.hip", "convblk.hip", "conv_mfma.hip"):
+        assert "-fno-slp-vectorize" in B.flags_for(os.path.join(B.CSRC, f)), f
+    assert "-fno-slp-vectorize" not in B.flags_for(os.path.join(B.CSRC, "iac.hip"))
+    if shutil.which(B.HIPCC) is None:
+        pytest.skip("hipcc not available")
+    asm = tmp_path / "fft.s"
+    subprocess.check_call([B.HIPCC, *B.flags_for(os.path.join(B.CSRC, "fft.hip")), "--cuda-device-only", "-S",
+                           "-I", os.path.join(B.HERE, "..", "include"), os.path.join(B.CSRC, "fft.hip"), "-o", str(asm)])
+    text = asm.read_text()
+    assert "ds_read_b128" in text and "v_pk_add_f32" not in text and "v_pk_mul_f32" not in text and "v_pk_fma_f32" not in text

@@ -29,8 +29,11 @@ static bool make_plan(int N, FftPlan* p) {
   p->nfac = 0;
   int n = N;
   // power-of-two radices first (their Ns stay powers of two), then 3, 5, then any other prime (generic butterfly)
+  // compound radices 8 (= 4 x 2) and 9 (= 3 x 3) are register butterflies too: one LDS round trip instead of two
+  while (n % 8 == 0) { p->fac[p->nfac++] = 8; n /= 8; }
   while (n % 4 == 0) { p->fac[p->nfac++] = 4; n /= 4; }
   while (n % 2 == 0) { p->fac[p->nfac++] = 2; n /= 2; }
+  while (n % 9 == 0) { p->fac[p->nfac++] = 9; n /= 9; }
   for (int f = 3; f <= n; f += 2) {
     while (n % f == 0) {
       if (p->nfac >= 20) return false;
@@ -64,6 +67,20 @@ __device__ __forceinline__ Cx csub(Cx a, Cx b) { return {a.r - b.r, a.i - b.i}; 
 __device__ __forceinline__ Cx cmul(Cx a, Cx w) { return {fmaf(a.r, w.r, -a.i * w.i), fmaf(a.r, w.i, a.i * w.r)}; }
 // multiply by -i (forward) or +i (inverse)
 template <bool INV> __device__ __forceinline__ Cx rot90(Cx a) { return INV ? Cx{-a.i, a.r} : Cx{a.i, -a.r}; }
+
+template <bool INV>
+__device__ __forceinline__ void dft3(Cx a, Cx b, Cx c, Cx& o0, Cx& o1, Cx& o2) {
+  const Cx t1 = cadd(b, c);
+  const Cx m = {a.r - 0.5f * t1.r, a.i - 0.5f * t1.i};
+  const Cx d0 = csub(b, c);
+  const Cx sd = rot90<INV>(Cx{0.86602540378443865f * d0.r, 0.86602540378443865f * d0.i});
+  o0 = cadd(a, t1); o1 = cadd(m, sd); o2 = csub(m, sd);
+}
+template <bool INV>
+__device__ __forceinline__ void dft4(Cx v0, Cx v1, Cx v2, Cx v3, Cx* o) {
+  const Cx a = cadd(v0, v2), b = csub(v0, v2), c = cadd(v1, v3), d = rot90<INV>(csub(v1, v3));
+  o[0] = cadd(a, c); o[2] = csub(a, c); o[1] = cadd(b, d); o[3] = csub(b, d);
+}
 
 // One Stockham stage with a register butterfly of compile-time radix R: thread = (butterfly j, channel lane l).
 // y[(jhi*Ns*R + k + p*Ns)] = sum_q x[j + q*M] * W_N^(q*k*mult) * W_R^(p*q),  k = j % Ns, jhi = j / Ns, M = N/R.
@@ -109,6 +126,32 @@ __device__ __forceinline__ void stage_radix(const float* xr, const float* xi, fl
       const Cx r1 = rot90<INV>(Cx{s1 * t3.r + s2 * t4.r, s1 * t3.i + s2 * t4.i});
       const Cx r2 = rot90<INV>(Cx{s2 * t3.r - s1 * t4.r, s2 * t3.i - s1 * t4.i});
       u[1] = cadd(m1, r1); u[4] = csub(m1, r1); u[2] = cadd(m2, r2); u[3] = csub(m2, r2);
+    } else if (R == 8) {
+      // radix 8 = DFT4 of the even and of the odd inputs, then W8^k on the odd half (forward W8 = e^{-i pi/4})
+      Cx e[4], o[4];
+      dft4<INV>(v[0], v[2], v[4], v[6], e);
+      dft4<INV>(v[1], v[3], v[5], v[7], o);
+      const float h = 0.70710678118654752f;
+      const Cx o1 = INV ? Cx{h * (o[1].r - o[1].i), h * (o[1].r + o[1].i)} : Cx{h * (o[1].r + o[1].i), h * (o[1].i - o[1].r)};
+      const Cx o2 = rot90<INV>(o[2]);
+      const Cx o3 = INV ? Cx{h * (-o[3].r - o[3].i), h * (o[3].r - o[3].i)} : Cx{h * (o[3].i - o[3].r), h * (-o[3].r - o[3].i)};
+      u[0] = cadd(e[0], o[0]); u[4] = csub(e[0], o[0]);
+      u[1] = cadd(e[1], o1);   u[5] = csub(e[1], o1);
+      u[2] = cadd(e[2], o2);   u[6] = csub(e[2], o2);
+      u[3] = cadd(e[3], o3);   u[7] = csub(e[3], o3);
+    } else if (R == 9) {
+      // radix 9 = 3 x 3: A[n2][k1] = DFT3 over n1 of v[3 n1 + n2]; times W9^(n2 k1); X[k1 + 3 k2] = DFT3 over n2
+      Cx A[3][3];
+#pragma unroll
+      for (int n2 = 0; n2 < 3; ++n2) dft3<INV>(v[n2], v[3 + n2], v[6 + n2], A[n2][0], A[n2][1], A[n2][2]);
+      const float c1 = 0.76604444311897804f, s1 = 0.64278760968653933f;      // 2 pi / 9
+      const float c2 = 0.17364817766693035f, s2 = 0.98480775301220806f;      // 4 pi / 9
+      const float c4 = -0.93969262078590838f, s4 = 0.34202014332566873f;     // 8 pi / 9
+      const Cx w1 = {c1, INV ? s1 : -s1}, w2 = {c2, INV ? s2 : -s2}, w4 = {c4, INV ? s4 : -s4};
+      A[1][1] = cmul(A[1][1], w1); A[1][2] = cmul(A[1][2], w2);
+      A[2][1] = cmul(A[2][1], w2); A[2][2] = cmul(A[2][2], w4);
+#pragma unroll
+      for (int k1 = 0; k1 < 3; ++k1) dft3<INV>(A[0][k1], A[1][k1], A[2][k1], u[k1], u[k1 + 3], u[k1 + 6]);
     }
     const int o0 = (jhi * Ns * R + k) * L + l;
 #pragma unroll
@@ -165,7 +208,9 @@ __device__ __forceinline__ int run_stages(float* lds, const FftPlan& plan, int L
     float* yr = lds + (cur ^ 1) * 2 * NL;
     float* yi = yr + NL;
     const unsigned mg = plan.magic[s];
-    if (r == 4) stage_radix<4, INV>(xr, xi, yr, yi, tw, N, Ns, mg, L, logL);
+    if (r == 8) stage_radix<8, INV>(xr, xi, yr, yi, tw, N, Ns, mg, L, logL);
+    else if (r == 9) stage_radix<9, INV>(xr, xi, yr, yi, tw, N, Ns, mg, L, logL);
+    else if (r == 4) stage_radix<4, INV>(xr, xi, yr, yi, tw, N, Ns, mg, L, logL);
     else if (r == 2) stage_radix<2, INV>(xr, xi, yr, yi, tw, N, Ns, mg, L, logL);
     else if (r == 3) stage_radix<3, INV>(xr, xi, yr, yi, tw, N, Ns, mg, L, logL);
     else if (r == 5) stage_radix<5, INV>(xr, xi, yr, yi, tw, N, Ns, mg, L, logL);

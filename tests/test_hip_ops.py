@@ -153,7 +153,8 @@ def test_conv_mfma_grouped_levels():
         assert float((nchw(g["dst"]) - ref).abs().max()) < 2e-5 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("H,W,n", [(180, 320, 64), (20, 24, 64), (144, 176, 16), (272, 480, 8), (17, 23, 5), (64, 64, 12)])
+@pytest.mark.parametrize("H,W,n", [(180, 320, 64), (20, 24, 64), (144, 176, 16), (272, 480, 8), (17, 23, 5), (64, 64, 12), (72, 81, 4),
+                                   (81, 512, 4)])
 def test_rfft2_irfft2_vs_torch(H, W, n):
     """Any length incl. primes 11/17/23 (Vid4 / CVCP sizes) and odd W; [imag, real] packing; c2r semantics."""
     from fcvsr_amd import hip

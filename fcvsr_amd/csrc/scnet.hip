@@ -390,7 +390,76 @@ struct XsLv {
 };
 struct XsArgs { XsLv lv[3]; int n; };
 
-template <int DT>
+// V quads (4 V channels) per thread: V = 2 in the 16-bit modes makes every access 16 bytes per lane
+template <int V> struct QuadV { float4 p[V]; };
+
+template <int DT, int V>
+__device__ __forceinline__ QuadV<V> ldq(const void* base, long long idx) {       // idx counts groups of V quads
+  QuadV<V> r;
+  if (V == 2 && DT != FCVSR_F32) {
+    const uint4 v = reinterpret_cast<const uint4*>(base)[idx];
+    if (DT == FCVSR_BF16) {
+      r.p[0] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                           __uint_as_float(v.y & 0xffff0000u));
+      r.p[V - 1] = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w << 16),
+                               __uint_as_float(v.w & 0xffff0000u));
+    } else {
+      typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+      const h2 a = __builtin_bit_cast(h2, v.x), b = __builtin_bit_cast(h2, v.y), c = __builtin_bit_cast(h2, v.z),
+               d = __builtin_bit_cast(h2, v.w);
+      r.p[0] = make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+      r.p[V - 1] = make_float4((float)c[0], (float)c[1], (float)d[0], (float)d[1]);
+    }
+    return r;
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) r.p[i] = ld4<DT>(base, idx * V + i);
+  return r;
+}
+
+template <int DT, int V>
+__device__ __forceinline__ void stq(void* base, long long idx, const QuadV<V>& x) {
+  if (V == 2 && DT != FCVSR_F32) {
+    uint4 o;
+    if (DT == FCVSR_BF16) {
+      typedef __attribute__((ext_vector_type(4))) __bf16 b4;
+      const b4 c0 = {(__bf16)x.p[0].x, (__bf16)x.p[0].y, (__bf16)x.p[0].z, (__bf16)x.p[0].w};
+      const b4 c1 = {(__bf16)x.p[V - 1].x, (__bf16)x.p[V - 1].y, (__bf16)x.p[V - 1].z, (__bf16)x.p[V - 1].w};
+      const uint2 u0 = __builtin_bit_cast(uint2, c0), u1 = __builtin_bit_cast(uint2, c1);
+      o = make_uint4(u0.x, u0.y, u1.x, u1.y);
+    } else {
+      typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+      const h4 c0 = {(_Float16)x.p[0].x, (_Float16)x.p[0].y, (_Float16)x.p[0].z, (_Float16)x.p[0].w};
+      const h4 c1 = {(_Float16)x.p[V - 1].x, (_Float16)x.p[V - 1].y, (_Float16)x.p[V - 1].z, (_Float16)x.p[V - 1].w};
+      const uint2 u0 = __builtin_bit_cast(uint2, c0), u1 = __builtin_bit_cast(uint2, c1);
+      o = make_uint4(u0.x, u0.y, u1.x, u1.y);
+    }
+    reinterpret_cast<uint4*>(base)[idx] = o;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) st4<DT>(base, idx * V + i, x.p[i]);
+}
+
+template <int V>
+__device__ __forceinline__ QuadV<V> qv_axpy(float a, const QuadV<V>& x, const QuadV<V>& y) {
+  QuadV<V> r;
+#pragma unroll
+  for (int i = 0; i < V; ++i) r.p[i] = f4_axpy(a, x.p[i], y.p[i]);
+  return r;
+}
+template <int V>
+__device__ __forceinline__ QuadV<V> qv_half_sum(const QuadV<V>& a, const QuadV<V>& b) {       // 0.5 a + 0.5 b, torch's order
+  QuadV<V> r;
+#pragma unroll
+  for (int i = 0; i < V; ++i)
+    r.p[i] = make_float4(0.5f * a.p[i].x + 0.5f * b.p[i].x, 0.5f * a.p[i].y + 0.5f * b.p[i].y,
+                         0.5f * a.p[i].z + 0.5f * b.p[i].z, 0.5f * a.p[i].w + 0.5f * b.p[i].w);
+  return r;
+}
+
+// Cq counts the per-pixel groups of V quads (C / (4 V))
+template <int DT, int V>
 __global__ void xscale_levels_kernel(XsArgs a, int Cq) {
   int li = 0;
   if (a.n > 1 && (int)blockIdx.x >= a.lv[1].blk_begin) li = 1;
@@ -405,22 +474,23 @@ __global__ void xscale_levels_kernel(XsArgs a, int Cq) {
   const int xx = (int)(pg % W);
   const int yy = (int)((pg / W) % H);
   const int b = (int)(pg / ((long long)W * H));
-  float4 acc = f4_axpy(L.rs, ld4<DT>(L.r, t), ld4<DT>(L.x, t));
+  QuadV<V> acc = qv_axpy<V>(L.rs, ldq<DT, V>(L.r, t), ldq<DT, V>(L.x, t));
   if (L.dn) {
     if (L.dn_pooled) {
-      const float4 d = ld4<DT>(L.dn, t);
-      acc = make_float4(acc.x + d.x, acc.y + d.y, acc.z + d.z, acc.w + d.w);
+      const QuadV<V> d = ldq<DT, V>(L.dn, t);
+#pragma unroll
+      for (int i = 0; i < V; ++i)
+        acc.p[i] = make_float4(acc.p[i].x + d.p[i].x, acc.p[i].y + d.p[i].y, acc.p[i].z + d.p[i].z, acc.p[i].w + d.p[i].w);
     } else {
       const int H2 = 2 * H, W2 = 2 * W;
       const long long d0 = ((long long)b * H2 * W2) * Cq + cq;
-      const float4 a00 = ld4<DT>(L.dn, d0 + ((long long)(2 * yy) * W2 + 2 * xx) * Cq);
-      const float4 a01 = ld4<DT>(L.dn, d0 + ((long long)(2 * yy) * W2 + 2 * xx + 1) * Cq);
-      const float4 a10 = ld4<DT>(L.dn, d0 + ((long long)(2 * yy + 1) * W2 + 2 * xx) * Cq);
-      const float4 a11 = ld4<DT>(L.dn, d0 + ((long long)(2 * yy + 1) * W2 + 2 * xx + 1) * Cq);
-      const float4 top = make_float4(0.5f * a00.x + 0.5f * a01.x, 0.5f * a00.y + 0.5f * a01.y, 0.5f * a00.z + 0.5f * a01.z, 0.5f * a00.w + 0.5f * a01.w);
-      const float4 bot = make_float4(0.5f * a10.x + 0.5f * a11.x, 0.5f * a10.y + 0.5f * a11.y, 0.5f * a10.z + 0.5f * a11.z, 0.5f * a10.w + 0.5f * a11.w);
-      acc = f4_axpy(0.5f, top, acc);
-      acc = f4_axpy(0.5f, bot, acc);
+      const QuadV<V> a00 = ldq<DT, V>(L.dn, d0 + ((long long)(2 * yy) * W2 + 2 * xx) * Cq);
+      const QuadV<V> a01 = ldq<DT, V>(L.dn, d0 + ((long long)(2 * yy) * W2 + 2 * xx + 1) * Cq);
+      const QuadV<V> a10 = ldq<DT, V>(L.dn, d0 + ((long long)(2 * yy + 1) * W2 + 2 * xx) * Cq);
+      const QuadV<V> a11 = ldq<DT, V>(L.dn, d0 + ((long long)(2 * yy + 1) * W2 + 2 * xx + 1) * Cq);
+      const QuadV<V> top = qv_half_sum<V>(a00, a01), bot = qv_half_sum<V>(a10, a11);
+      acc = qv_axpy<V>(0.5f, top, acc);
+      acc = qv_axpy<V>(0.5f, bot, acc);
     }
   }
   if (L.up) {
@@ -431,15 +501,15 @@ __global__ void xscale_levels_kernel(XsArgs a, int Cq) {
     const int y1 = y0 + (y0 < Hh - 1 ? 1 : 0), x1 = x0 + (x0 < Wh - 1 ? 1 : 0);
     const float ly = sy - (float)y0, lx = sx - (float)x0;
     const long long u0 = ((long long)b * Hh * Wh) * Cq + cq;
-    const float4 u00 = ld4<DT>(L.up, u0 + ((long long)y0 * Wh + x0) * Cq), u01 = ld4<DT>(L.up, u0 + ((long long)y0 * Wh + x1) * Cq);
-    const float4 u10 = ld4<DT>(L.up, u0 + ((long long)y1 * Wh + x0) * Cq), u11 = ld4<DT>(L.up, u0 + ((long long)y1 * Wh + x1) * Cq);
+    const QuadV<V> u00 = ldq<DT, V>(L.up, u0 + ((long long)y0 * Wh + x0) * Cq), u01 = ldq<DT, V>(L.up, u0 + ((long long)y0 * Wh + x1) * Cq);
+    const QuadV<V> u10 = ldq<DT, V>(L.up, u0 + ((long long)y1 * Wh + x0) * Cq), u11 = ldq<DT, V>(L.up, u0 + ((long long)y1 * Wh + x1) * Cq);
     const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
-    acc = f4_axpy(w00, u00, acc);
-    acc = f4_axpy(w01, u01, acc);
-    acc = f4_axpy(w10, u10, acc);
-    acc = f4_axpy(w11, u11, acc);
+    acc = qv_axpy<V>(w00, u00, acc);
+    acc = qv_axpy<V>(w01, u01, acc);
+    acc = qv_axpy<V>(w10, u10, acc);
+    acc = qv_axpy<V>(w11, u11, acc);
   }
-  st4<DT>(L.out, t, acc);
+  stq<DT, V>(L.out, t, acc);
 }
 
 }  // namespace fcvsr
@@ -579,6 +649,7 @@ extern "C" int fcvsr_xscale_levels(const fcvsr_xscale_level* lv, int n_levels, i
   XsArgs a;
   a.n = n_levels;
   int blocks = 0;
+  const int V = (io_dtype != FCVSR_F32 && C % 8 == 0) ? 2 : 1;         // 16-byte accesses in the 16-bit modes
   for (int l = 0; l < 3; ++l) {
     const fcvsr_xscale_level& s = lv[l < n_levels ? l : 0];
     FCVSR_CHECK_ARG(s.x && s.r && s.out && s.B > 0 && s.H > 0 && s.W > 0, "null level");
@@ -587,12 +658,14 @@ extern "C" int fcvsr_xscale_levels(const fcvsr_xscale_level* lv, int n_levels, i
     XsLv& d = a.lv[l];
     d.x = s.x; d.r = s.r; d.dn = s.dn; d.up = s.up; d.out = s.out; d.rs = s.r_scale; d.dn_pooled = s.dn_pooled;
     d.B = s.B; d.H = s.H; d.W = s.W; d.blk_begin = blocks;
-    if (l < n_levels) blocks += cdiv((long long)s.B * s.H * s.W * (C / 4), 256);
+    if (l < n_levels) blocks += cdiv((long long)s.B * s.H * s.W * (C / (4 * V)), 256);
   }
   hipStream_t st = (hipStream_t)stream;
-  if (io_dtype == FCVSR_F32) hipLaunchKernelGGL((xscale_levels_kernel<FCVSR_F32>), dim3(blocks), dim3(256), 0, st, a, C / 4);
-  else if (io_dtype == FCVSR_BF16) hipLaunchKernelGGL((xscale_levels_kernel<FCVSR_BF16>), dim3(blocks), dim3(256), 0, st, a, C / 4);
-  else hipLaunchKernelGGL((xscale_levels_kernel<FCVSR_F16>), dim3(blocks), dim3(256), 0, st, a, C / 4);
+#define FCVSR_XSL(DTV, VV) hipLaunchKernelGGL((xscale_levels_kernel<DTV, VV>), dim3(blocks), dim3(256), 0, st, a, C / (4 * VV))
+  if (io_dtype == FCVSR_F32) FCVSR_XSL(FCVSR_F32, 1);
+  else if (io_dtype == FCVSR_BF16) { if (V == 2) FCVSR_XSL(FCVSR_BF16, 2); else FCVSR_XSL(FCVSR_BF16, 1); }
+  else { if (V == 2) FCVSR_XSL(FCVSR_F16, 2); else FCVSR_XSL(FCVSR_F16, 1); }
+#undef FCVSR_XSL
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

@@ -611,6 +611,8 @@ class Engine:
                 t = self._block_rcb(f"recorb1.body.{g}.body.{k}", t)
             last = g == m.SCGroupN - 1
             # the trunk may be 16-bit (trunk16); SCNetbk's outputs leave in f32
+            # (the net outputs stay f32: upconv_fuse concatenates o0 with two narrow f32 tensors and a launch takes sources
+            # of one dtype)
             nxt = [torch.empty_like(c, dtype=torch.float32 if last else c.dtype) for c in cur]
             # fold SCNetbk's outer skip (x + body(x), :817-821) into the last group conv's epilogue
             grp = [dict(srcs=[t[l]], dst=nxt[l], res=([cur[l], xs[l]] if last else [cur[l]])) for l in range(3)]
@@ -751,7 +753,7 @@ class Engine:
         l2p = self._new(dev, B, H, W, n // 4)
         self._conv("upconv1_L2_2", [l2, l3_1], l2p, res=[l2], ps=True)
         fz0 = self._new(dev, B, H, W, n, dtype=self._adt())
-        fz = self._new(dev, B, H, W, n)
+        fz = self._new(dev, B, H, W, n, dtype=self._adt())          # read only by upconv1 (MFMA)
         self._conv("upconv_fuse", [o0, l2p, l3_2], fz0)
         self._conv("recorb0", [fz0], fz)
         self._tap("fz", fz)

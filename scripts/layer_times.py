@@ -20,8 +20,8 @@ agg = collections.OrderedDict()
 for e0, e1, fl, kind, name, _nb, _var in recs:
     key = re.sub(r"body\.\d+\.body\.\d+", "body.G.body.K", name); key = re.sub(r"body\.\d+\.conv", "body.G.conv", key)
     key = re.sub(r"MConvB\.\d+", "MConvB.I", key)
-    a = agg.setdefault((key, kind), [0, 0.0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1) * 1e3; a[2] += fl
+    a = agg.setdefault((key, kind + ":" + str(_var)), [0, 0.0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1) * 1e3; a[2] += fl
 tot = sum(a[1] for a in agg.values())
 print(f"B={B} prec={prec}: total conv time {tot/1e3:.2f} ms over {len(recs)} launches")
 for (k, kind), (n, us, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print(f"{k:42s} {kind:6s} n={n:3d} {us:9.1f} us  avg {us/n:8.1f} us  {fl/us/1e6 if us else 0:7.1f} TF/s")
+    print(f"{k:42s} {kind:20s} n={n:3d} {us:9.1f} us  avg {us/n:8.1f} us  {fl/us/1e6 if us else 0:7.1f} TF/s")

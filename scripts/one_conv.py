@@ -7,7 +7,8 @@ L3 = [(180, 320), (90, 160), (45, 80)]
 B, cin, cout = 8, 64, 64
 w = torch.randn(cout, cin, 3, 3, device="cuda") / 24
 wp = hip.pack_conv_weight_mfma(w, dt)
-groups = [dict(srcs=[torch.randn(B, H, W, cin, device="cuda")], dst=torch.empty(B, H, W, cout, device="cuda")) for H, W in L3]
+io = torch.bfloat16 if os.environ.get("IO16", "1") == "1" else torch.float32       # default: the bench's dominant variant
+groups = [dict(srcs=[torch.randn(B, H, W, cin, device="cuda").to(io)], dst=torch.empty(B, H, W, cout, device="cuda", dtype=io)) for H, W in L3]
 for _ in range(5):
     hip.conv2d_mfma(groups, wp, 3, cout, mdt, act=hip.ACT_LEAKY, slope=0.1)
 torch.cuda.synchronize()

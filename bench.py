@@ -46,6 +46,61 @@ def host_threads() -> int:
     return max(1, min(n, 16))
 
 
+def stub_run(args, world, rank):
+    """No-GPU rehearsal of the rank protocol (rendezvous, barrier, max-over-ranks, rank 0 prints one line)."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(args.backend if args.backend != "nccl" else "gloo")
+    x = torch.zeros(args.batch, 7, 1, 8, 8)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = x + 1.0
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": world * args.batch * args.steps / max(float(t), 1e-9), "unit": "frames/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "data": "stub", "scaling": "weak"}),
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: start N fresh rank processes (one per GPU) BEFORE this
+    process touches the GPU, relay their output (rank 0 prints the JSON line on stdout) and return non-zero if any fails.
+    Same environment contract as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` (reference launcher
+    shape: mmedit_train/tools/dist_train.sh:10-19)."""
+    import subprocess
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for r, p in enumerate(procs):
+        c = p.wait()
+        if c != 0:
+            log(f"rank {r} exited with code {c}")
+            rc = rc or c
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,7 +119,13 @@ def main():
     ap.add_argument("--device", type=int, default=None, help="override the HIP device index (rehearsing N ranks on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sub-records (batch-1 latency, full model, f32 mode)")
+    ap.add_argument("--stub", action="store_true",
+                    help="launch-plumbing rehearsal without a GPU: the step is a no-op on CPU tensors and the line says so "
+                         "(metric 'stub'); used by tests/test_dist_cpu.py with --backend gloo")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import numpy as np
     import torch
@@ -74,8 +135,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks for --gpus N")
+    if args.stub:
+        return stub_run(args, world, rank)
     local = local if args.device is None else args.device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -130,15 +192,21 @@ def main():
     fps = frames / dt
 
     roofline = None
+    timed_equals_eager = None
     if not args.no_roofline:
         # Dominant kernel class = the convolution kernel (>= 98 % of FLOPs).  One extra instrumented step: every conv launch
         # is bracketed by HIP events on the launch stream; achieved = sum(algorithmic FLOPs) / sum(durations).
         hip.PROFILE = []
         model.streams, model.use_graph = 1, False          # one stream, eager launches: isolated per-launch durations
         with torch.no_grad():
-            model(x)
+            y_eager = model(x)
         torch.cuda.synchronize()
         model.streams, model.use_graph = args.streams, bool(args.graph)
+        # the timed configuration (hipGraph replay, sub-batches on several streams) must reproduce the eager single-stream
+        # launches bit for bit: clips are independent and every reduction of the path has a fixed order
+        timed_equals_eager = bool(torch.equal(y, y_eager))
+        assert timed_equals_eager, (f"timed configuration differs from the eager single-stream forward: max-abs "
+                                    f"{float((y - y_eager).abs().max()):.3e}")
         recs = hip.PROFILE
         hip.PROFILE = None
         # Dominant kernel (largest share of the step, see profiles/): conv3_lean_kernel<BF16, 64, SRC16, DST16>, the lean 3x3
@@ -177,14 +245,15 @@ def main():
                                          "launches_per_step": len(cls), "ms_per_step": round(cls_ms, 3)}}
 
     cpu = None
+    parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import fcvsr_oracle as O                  # CPU baseline leg only: the oracle as a timed "port"
+        from oracle import fcvsr_oracle as O                  # checker + CPU baseline leg only (never the timed path)
         ncpu = host_threads()
         torch.set_num_threads(ncpu)
         log(f"cpu baseline: oracle on {ncpu} threads")
         xc = x[:1].cpu()
         with torch.no_grad():
-            O.forward(sd, xc)
+            ref0 = O.forward(sd, xc)
             ts = []
             for _ in range(3):
                 t1 = time.perf_counter()
@@ -193,10 +262,57 @@ def main():
                 log(f"cpu baseline run {ts[-1]:.2f} s")
         cpu = {"value": round(1.0 / float(np.median(ts)), 4), "unit": "frames/s", "cores": torch.get_num_threads(),
                "kind": "port", "sample": f"3 forwards of one {H}x{W} 7-frame window (median), fp32 torch CPU oracle"}
+        # the PSNR half of the metric: the TIMED output of clip 0 against the CPU oracle (reference arithmetic in fp32) on
+        # the same input and weights; [0,255] scale, formula of CVSR_train/metric/psnr_ssim.py:314-317
+        d = (y[:1].detach().cpu().double() - ref0.double())
+        mse = float((d * 255.0).pow(2).mean())
+        parity = {"psnr_vs_oracle_db": round(float(20 * np.log10(255.0 / np.sqrt(mse))) if mse > 0 else 999.0, 3),
+                  "max_abs": float(d.abs().max()), "clip": 0, "scale": "[0,1] for max_abs, [0,255] for PSNR",
+                  "timed_equals_eager_single_stream_bitwise": timed_equals_eager}
+        log(f"parity vs oracle: {parity}")
+
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = {}
+
+        def timeit(mdl, xin, nw, nt):
+            with torch.no_grad():
+                for _ in range(nw):
+                    mdl(xin)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(nt):
+                    o = mdl(xin)
+                torch.cuda.synchronize()
+            assert bool(torch.isfinite(o).all())
+            return (time.perf_counter() - t1) / nt
+
+        # latency of ONE window (the reference's own FPS script times batch 1, test_LD_freqCVSR_S_FPS.py:62-74)
+        model.streams = 1
+        extras["batch1_ms"] = round(timeit(model, x[:1], 3, 20) * 1e3, 3)
+        # exact-f32 mode of the same model (the mode that meets the 1e-4 max-abs gate)
+        model.precision = "f32"
+        extras["f32_fps"] = round(B / timeit(model, x, 1, 2), 2)
+        with torch.no_grad():
+            yf = model(x[:1])
+        if not args.no_cpu_baseline:
+            extras["f32_max_abs_vs_oracle"] = float((yf.cpu() - ref0).abs().max())
+        model.precision, model.streams = args.precision, args.streams
+        del yf
+        if args.model == "S":
+            # the full model (BASELINE configs 2 / 4) with the same settings
+            log("extras: full model")
+            fm = A.GShiftNet()
+            fm.load_state_dict(synthetic_state_dict(state_dict_shapes("GShiftNet"), gain=0.5), strict=True)
+            fm = fm.to(dev)
+            fm.precision, fm.streams, fm.use_graph, fm.trunk16 = args.precision, args.streams, bool(args.graph), bool(args.trunk16)
+            extras["full_model_fps"] = round(B / timeit(fm, x, 1, 3), 2)
+            del fm
+        log(f"extras: {extras}")
 
     if rank == 0:
         line = {
-            "metric": "SR frames/sec (7-frame window, 4x 180x320->720x1280)", "value": round(fps, 3),
+            "metric": "SR frames/sec (7-frame window, 4x 180x320->720x1280) + PSNR vs ref", "value": round(fps, 3),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
@@ -205,7 +321,7 @@ def main():
                        "parallelism": f"clip-dp{world}"},
             "frames_per_sec_per_gpu": round(fps / world, 3),
             "conv_tflops_end_to_end": round(fps * conv_flops_live(args.model, H, W) / 1e12, 3),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "extras": extras,
         }
         print(json.dumps(line))
     if world > 1:

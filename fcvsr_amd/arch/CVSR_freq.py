@@ -209,6 +209,15 @@ class _GShiftBase(nn.Module):
         self.fuse_freq_head = os.environ.get("FCVSR_FUSE_FREQ_HEAD", "1") == "1"
         # capture the launch sequence of a forward in a hipGraph (per input shape) and replay it
         self.use_graph = os.environ.get("FCVSR_GRAPH", "0") == "1"
+        # captured graphs kept per (shape, precision, streams, flags): least-recently-used entries beyond this are freed
+        self.graph_cache_size = 4
+
+    def invalidate(self) -> None:
+        """Forget every cached re-packed weight / captured hipGraph.  Needed only after in-place edits through
+        ``param.data`` (EMA hooks, ``w.data.mul_()``): those do not bump ``Parameter._version``, which - with the
+        storage pointer - keys the caches.  ``load_state_dict``, optimizer steps and ``.to()`` are detected."""
+        if self._engine is not None:
+            self._engine.invalidate()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: float (B, 7, C, H, W) in [0,1] on a HIP device -> (B, C, 4H, 4W)."""

@@ -15,6 +15,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import weakref
+from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -62,7 +63,8 @@ class Engine:
         self._dev_masks: Dict[Tuple, torch.Tensor] = {}
         self._par: Dict[str, torch.Tensor] = {}
         self._streams: List[torch.cuda.Stream] = []
-        self._graphs: Dict[Tuple, Tuple] = {}
+        self._graphs: "OrderedDict[Tuple, Tuple]" = OrderedDict()
+        self._warm: set = set()                # configurations whose cached tensors exist (built on the caller's stream)
         self._pack_epoch = 0
         self._warned = False
         self.taps: Optional[dict] = None       # set to a dict to record NCHW copies of intermediate results (tests)
@@ -75,6 +77,16 @@ class Engine:
         return p
 
     # ---------------------------------------------------------------------------------------------- weights
+    def invalidate(self):
+        """Drop every cached re-packed weight and captured hipGraph.  The caches are keyed on (Parameter._version, data_ptr),
+        which in-place edits through ``param.data`` (EMA hooks, ``w.data *= s``) do not change: call this (or
+        ``model.invalidate()``) after such an edit."""
+        self._versions = None
+        self._packed = {}
+        self._graphs.clear()
+        self._warm.clear()
+        self._pack_epoch += 1
+
     def _refresh(self, dev):
         m = self._model()
         sd = {k: v for k, v in m.named_parameters()}
@@ -88,6 +100,8 @@ class Engine:
                 raise RuntimeError(f"parameter {k} is {v.dtype}: keep the parameters in float32 and select the arithmetic "
                                    "with model.precision = 'bf16' | 'f16' instead of casting the module")
         self._packed = {}
+        self._graphs.clear()
+        self._warm.clear()
         self._pack_epoch += 1
         self._par = sd
         self._versions = ver
@@ -647,23 +661,40 @@ class Engine:
             x = x.contiguous().float()
             self._refresh(dev)
             ns = max(1, min(int(getattr(m, "streams", 1)), B))
+            flags = tuple(bool(getattr(m, f, True)) for f in ("trunk16", "fold_f1", "fuse_tail", "pool_first", "fuse_freq_mlp",
+                                                              "fuse_freq_head", "fast_feat", "fuse_rcb_tail"))
+            cfg = (tuple(x.shape[1:]), self.precision, str(dev), self._pack_epoch, flags)
+            if ns > 1 and cfg not in self._warm:
+                # First pass of a configuration: re-packed weights, band masks and per-kernel attributes are created lazily
+                # inside the forward.  They must be built on the CALLER's stream, before the fan-out: side streams are only
+                # ordered after the caller's stream, not after each other, so a tensor first written on side stream 0
+                # would be read by the other side streams with no dependency (and would live in stream 0's allocator pool).
+                out = self._run(x, m, 1, dev)
+                self._warm.add(cfg)
+                if not getattr(m, "use_graph", False) or self.taps is not None or hip.PROFILE is not None:
+                    return out
+            self._warm.add(cfg)
             if not getattr(m, "use_graph", False) or self.taps is not None or hip.PROFILE is not None:
                 return self._run(x, m, ns, dev)
             # hipGraph mode: the ~650 launches of one forward are captured once per (shape, precision, streams, weights
             # version) and replayed, which removes the host launch cost (~9 us per ctypes launch) from the critical path.
-            key = (tuple(x.shape), self.precision, ns, str(dev), self._pack_epoch,
-                   tuple(bool(getattr(m, f, True)) for f in ("trunk16", "fold_f1", "fuse_tail", "pool_first", "fuse_freq_mlp", "fuse_freq_head", "fast_feat")))
+            key = (tuple(x.shape), ns) + cfg[1:]
             ent = self._graphs.get(key)
             if ent is None:
                 sx = x.clone()
-                for _ in range(2):                       # eager warm-up: weight packing, masks, function attributes
+                for _ in range(2):                       # eager warm-up on the capture configuration
                     self._run(sx, m, ns, dev)
                 torch.cuda.synchronize(dev)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     so = self._run(sx, m, ns, dev)
-                self._graphs = {k: v for k, v in self._graphs.items() if k[4] == self._pack_epoch}
+                # bounded cache: each entry pins a captured graph, its private memory pool and static in/out tensors
+                # (ragged last batches and new resolutions would otherwise grow it without bound)
+                while len(self._graphs) >= max(1, int(getattr(m, "graph_cache_size", 4))):
+                    self._graphs.popitem(last=False)
                 ent = self._graphs[key] = (graph, sx, so)
+            else:
+                self._graphs.move_to_end(key)
             graph, sx, so = ent
             sx.copy_(x)
             graph.replay()

@@ -93,3 +93,26 @@ def test_config1_bench_shape_against_oracle():
             psnr = 20 * np.log10(255 / np.sqrt(mse))
             assert psnr >= min_psnr, (prec, psnr)
             assert 10 * np.log10(1 + 10 ** ((30.0 - psnr) / 10)) < 0.01
+
+
+def test_config1_timed_configuration_b16_streams4_graph():
+    """What bench.py times - batch 16, 4 HIP streams, hipGraph replay, bf16 operands, 16-bit activation storage, 180x320 -
+    equals, bit for bit, the eager single-stream forward of each clip on its own (B = 1): clips are independent and every
+    reduction of the path has a fixed order that does not depend on the batch a clip travels in."""
+    from fcvsr_amd.arch.CVSR_freq import GShiftNet_S
+    from fcvsr_amd.arch.schema import state_dict_shapes
+    from fcvsr_amd.weights import synthetic_state_dict
+    model = GShiftNet_S()
+    model.load_state_dict(synthetic_state_dict(state_dict_shapes("GShiftNet_S"), gain=0.5))
+    model = model.cuda()
+    model.precision = "bf16"
+    x = torch.from_numpy(np.random.RandomState(1).rand(16, 7, 1, 180, 320).astype(np.float32)).cuda()
+    with torch.no_grad():
+        model.streams, model.use_graph = 4, True
+        y = model(x).clone()
+        y_replay = model(x).clone()
+        assert torch.equal(y, y_replay)
+        model.streams, model.use_graph = 1, False
+        for b in (0, 5, 15):
+            yb = model(x[b:b + 1])
+            assert torch.equal(yb[0], y[b]), b

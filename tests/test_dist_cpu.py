@@ -54,3 +54,38 @@ def test_two_rank_sharding_covers_every_frame_once():
     from fcvsr_amd.harness.sharding import shard, throughput
     assert [shard(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert throughput([138, 137], [0.5, 0.75]) == 275 / 0.75
+
+
+def test_bench_self_launches_its_ranks_with_gloo():
+    """`python bench.py --gpus 2` outside torch.distributed.run must start its own rank processes (before any GPU call),
+    relay rank 0's JSON line and exit 0; --stub replaces the GPU step by a no-op so the plumbing runs without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub",
+                        "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout                        # exactly one JSON line, from rank 0
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["data"] == "stub"
+    # the same entry point under the driver's launcher form
+    port = _free_port()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend",
+                        "gloo", "--stub", "--steps", "2", "--warmup", "0"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert sum(l.startswith("{") for l in p.stdout.splitlines()) == 1
+
+
+def test_bench_rejects_world_size_mismatch():
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0

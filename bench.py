@@ -209,12 +209,18 @@ def main():
                                     f"{float((y - y_eager).abs().max()):.3e}")
         recs = hip.PROFILE
         hip.PROFILE = None
-        # Dominant kernel (largest share of the step, see profiles/): conv3_lean_kernel<BF16, 64, SRC16, DST16>, the lean 3x3
-        # MFMA kernel with 16-bit source and destination (BlockRCB / RCB bodies, conv_KP, F.0, conv3, group convs).  In the
-        # exact-f32 mode the dominant kernel is the direct VALU convolution instead.
-        var = "direct" if args.precision == "f32" else "conv3_lean16"
-        dom = [r for r in recs if r[6] == var]
+        # Dominant kernel = the convolution kernel with the largest share of the step's GPU time.  Every record carries the
+        # name of the kernel the dispatcher really launched (fcvsr_last_conv_kernel), so this follows dispatcher changes:
+        # the LDS-resident-weight 3x3 kernel conv3_res_kernel<BF16, DST16, NCH> for the 64 / 128-channel layers at batch
+        # sizes that amortise its weight copy, conv3_lean_kernel otherwise; conv_direct_kernel in the exact-f32 mode.
         cls = [r for r in recs if r[3] == ("direct" if args.precision == "f32" else "mfma")]
+        by_kernel = {}
+        for r in cls:
+            kn = r[6] if r[3] == "mfma" else "conv_direct_kernel"
+            by_kernel.setdefault(kn, []).append(r)
+        kernel_ms = {kn: sum(r[0].elapsed_time(r[1]) for r in rs) for kn, rs in by_kernel.items()}
+        var = max(kernel_ms, key=kernel_ms.get)
+        dom = by_kernel[var]
         tot_ms = sum(r[0].elapsed_time(r[1]) for r in dom)
         tot_fl = sum(r[2] for r in dom)
         cls_ms = sum(r[0].elapsed_time(r[1]) for r in cls)
@@ -222,12 +228,12 @@ def main():
         peak = PEAK_TFLOPS[args.precision]
         ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         traffic = None
-        try:        # HBM bytes per launch from the committed PMC passes (same workload), see profiles/r01_pmc_traffic.json
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        try:        # HBM bytes per launch from the committed PMC passes (same workload), see profiles/pmc_traffic.json
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pm = json.load(f)
             c = pm["config"]
             if (c["model"], c["batch"], c["precision"], c["height"], c["width"], c.get("act16", False)) == \
-                    (args.model, B, args.precision, H, W, bool(args.trunk16)) and var == "conv3_lean16":
+                    (args.model, B, args.precision, H, W, bool(args.trunk16)) and var == pm.get("kernel", "").replace("void fcvsr::", ""):
                 traffic = round(pm["hbm_bytes_per_launch"])
         except Exception:
             traffic = None
@@ -236,11 +242,11 @@ def main():
                     "frac": round(ach / peak, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": round(sum(r[5] for r in dom) / n_dom),
                     "algorithmic_flops_per_launch": round(tot_fl / n_dom),
-                    "kernel": "conv_direct_kernel" if var == "direct" else
-                              f"conv3_lean_kernel<{'true' if args.precision == 'bf16' else 'false'}, 64, true, true>",
+                    "kernel": var,
                     "launches_per_step": len(dom), "avg_launch_us": round(tot_ms * 1e3 / n_dom, 2),
                     "kernel_ms_per_step": round(tot_ms, 3),
                     "how": "one extra single-stream eager step, HIP events around every launch on the launch stream",
+                    "conv_kernels_ms_per_step": {kn: round(v, 3) for kn, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])},
                     "all_conv_kernels": {"tflops": round(cls_fl / (cls_ms * 1e-3) / 1e12, 3) if cls_ms > 0 else 0.0,
                                          "launches_per_step": len(cls), "ms_per_step": round(cls_ms, 3)}}
 

@@ -21,7 +21,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "mfma_util.h"
-#include "conv_ws.h"
+#include "conv_res.h"
 
 namespace fcvsr {
 
@@ -1172,6 +1172,12 @@ static hipError_t dispatch(const MfmaArgs& a, int nt, int ks, int mw, int wd, in
 
 using namespace fcvsr;
 
+// name of the kernel the last fcvsr_conv2d_mfma call of this thread launched (bench.py groups its per-launch timings by it)
+static thread_local char g_last_kernel[96] = "";
+extern "C" const char* fcvsr_last_conv_kernel(void) { return g_last_kernel; }
+#define FCVSR_NOTE_KERNEL(...) snprintf(g_last_kernel, sizeof(g_last_kernel), __VA_ARGS__)
+static const char* tf(int v) { return v ? "true" : "false"; }
+
 // channel-contiguous res/dst views are accessed 16 bytes at a time
 static bool vec_view_ok(const fcvsr_view& v) {
   const int g = v.dtype == FCVSR_F32 ? 4 : 8;   // 16-byte granules for f32 quads, 8-byte for 16-bit quads (keep 16 for safety)
@@ -1348,6 +1354,7 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   }
   hipError_t e;
   if (lean1) {
+    FCVSR_NOTE_KERNEL("conv1_lean_kernel<%s, %d, %s, %s, %s>", tf(mma_dtype == FCVSR_BF16), nt, tf(a.src16), tf(a.dst16), tf(a.ps));
     e = (mma_dtype == FCVSR_BF16) ? dispatch_lean1<true>(a, nt, tiles, st) : dispatch_lean1<false>(a, nt, tiles, st);
     if (e != hipSuccess) {
       set_error("fcvsr_conv2d_mfma: launch failed: %s", hipGetErrorString(e));
@@ -1355,22 +1362,33 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
     }
     return 0;
   }
-  // weight-stationary persistent kernel (conv_ws.hip): 16-bit dense source of exactly 64 channels, cout 64/128/256,
-  // channel-contiguous destination and residuals, no ContextBlock fusion
-  bool ws = lean && a.src16 && conv3_ws_supports(cin, d0.cout) && d0.gc_wmask == nullptr;
-  for (int g = 0; g < n_groups && ws; ++g) {
+  // LDS-resident-weight persistent kernel (conv_res.hip): one dense 16-bit source of 64 or 128 channels, cout a multiple of
+  // 64, channel-contiguous 16-byte-aligned destination and residuals, no ContextBlock fusion.  It pays once every workgroup
+  // amortises its 72 KiB weight copy over a few 8 x 32 tiles; small launches stay on the lean kernel.
+  bool res = lean && a.src16 && conv3_res_supports(cin, d0.cout) && d0.gc_wmask == nullptr && d0.cout == d0.cout / 64 * 64;
+  int rtiles = 0;
+  for (int g = 0; g < n_groups && res; ++g) {
     const fcvsr_conv_desc& d = descs[g];
-    ws = ws && d.dst.sc == 1 && d.dst.sx % 4 == 0;
-    for (int q = 0; q < d.n_res; ++q) ws = ws && d.res[q].sc == 1;
+    const int dg = a.dst16 ? 8 : 4;
+    res = res && d.dst.sc == 1 && d.dst.sx % dg == 0 && d.dst.sy % dg == 0 && d.dst.sb % dg == 0 && ((uintptr_t)d.dst.ptr % 16) == 0;
+    res = res && d.src[0].sx % 8 == 0 && d.src[0].sy % 8 == 0 && d.src[0].sb % 8 == 0;
+    for (int q = 0; q < d.n_res; ++q) {
+      const int rg = d.res[q].dtype == FCVSR_F32 ? 4 : 8;
+      res = res && d.res[q].sc == 1 && d.res[q].sx % rg == 0 && d.res[q].sy % rg == 0 && d.res[q].sb % rg == 0 &&
+            ((uintptr_t)d.res[q].ptr % 16) == 0;
+    }
+    rtiles += conv3_res_tiles(d.B, d.H, d.W);
   }
   {
-    // Experimental, off by default: measured 0.75-0.9x of the lean kernel on the path's shapes ("weight-stationary
-    // experiment") - two waves per SIMD cannot hide the epilogue / staging phases that 4-5 co-resident lean workgroups overlap.
-    const char* e3 = getenv("FCVSR_MFMA_WS");
-    if (!e3 || atoi(e3) == 0) ws = false;
+    // FCVSR_MFMA_RES: 0 never, 1 always (when eligible), unset: by size (FCVSR_MFMA_RES_MIN workgroup-tiles)
+    const char* e3 = getenv("FCVSR_MFMA_RES");
+    const int res_mode = e3 ? (atoi(e3) ? 1 : 0) : 2;
+    const char* e4 = getenv("FCVSR_MFMA_RES_MIN");
+    const int res_min = e4 ? atoi(e4) : 768;
+    if (res_mode == 0 || (res_mode == 2 && rtiles * (cin == 64 ? d0.cout / 64 : d0.cout / 32) < res_min)) res = false;
   }
-  if (ws) {
-    static void* zeros = nullptr;
+  if (res) {
+    static void* zeros = nullptr;                    // per process; allocated outside any stream capture by Engine warm-up
     if (!zeros) {
       hipError_t ez = hipMalloc(&zeros, 256);
       if (ez == hipSuccess) ez = hipMemset(zeros, 0, 256);
@@ -1380,16 +1398,16 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
         return (int)ez;
       }
     }
-    WsArgs wa;
+    ResArgs wa;
     wa.n_groups = n_groups;
     int wtiles = 0;
     for (int g = 0; g < 3; ++g) {
       const MGroup& G = a.g[g < n_groups ? g : 0];
-      WsGroup& Wg = wa.g[g];
+      ResGroup& Wg = wa.g[g];
       Wg.src = G.src[0]; Wg.res[0] = G.res[0]; Wg.res[1] = G.res[1]; Wg.dst = G.dst; Wg.gc_partial = nullptr;
       Wg.B = G.B; Wg.H = G.H; Wg.W = G.W;
       Wg.tiles_x = cdiv(G.W, 32);
-      Wg.tiles_y = cdiv(G.H, 4);
+      Wg.tiles_y = cdiv(G.H, 8);
       Wg.tile_begin = wtiles;
       if (g < n_groups) wtiles += G.B * Wg.tiles_x * Wg.tiles_y;
     }
@@ -1397,10 +1415,11 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
     wa.cin = cin; wa.cout = d0.cout; wa.cout_pad = d0.cout_pad; wa.cin_pad = a.cin_pad;
     wa.w = a.w; wa.bias = a.bias; wa.act = a.act; wa.slope = a.slope; wa.slope_ptr = a.slope_ptr;
     wa.rs[0] = a.rs[0]; wa.rs[1] = a.rs[1]; wa.n_res = a.n_res; wa.res16 = a.res16; wa.zeros = zeros;
-    { const char* wd_ = getenv("FCVSR_WS_DBG"); wa.dbg = wd_ ? atoi(wd_) : 0; }
-    e = launch_conv3_ws(wa, mma_dtype == FCVSR_BF16, a.dst16 != 0, st);
+    { const char* wd_ = getenv("FCVSR_RES_DBG"); wa.dbg = wd_ ? atoi(wd_) : 0; }
+    FCVSR_NOTE_KERNEL("conv3_res_kernel<%s, %s, %d>", tf(mma_dtype == FCVSR_BF16), tf(a.dst16), cin / 64);
+    e = launch_conv3_res(wa, mma_dtype == FCVSR_BF16, a.dst16 != 0, st);
     if (e != hipSuccess) {
-      set_error("fcvsr_conv2d_mfma: weight-stationary launch failed: %s", hipGetErrorString(e));
+      set_error("fcvsr_conv2d_mfma: resident-weight launch failed: %s", hipGetErrorString(e));
       return (int)e;
     }
     return 0;
@@ -1409,6 +1428,8 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
     nt = 64;
     a.n_nblk = (d0.cout + nt - 1) / nt;
   }
+  if (lean) FCVSR_NOTE_KERNEL("conv3_lean_kernel<%s, %d, %s, %s>%s", tf(mma_dtype == FCVSR_BF16), nt, tf(a.src16), tf(a.dst16), a.gc_wmask ? " +gc" : "");
+  else FCVSR_NOTE_KERNEL("conv_mfma_kernel<%s, %d, %d, %d, %s>", tf(mma_dtype == FCVSR_BF16), nt, d0.kh, mw, tf(wd));
   if (lean) e = (mma_dtype == FCVSR_BF16) ? dispatch_lean<true>(a, nt, tiles, st) : dispatch_lean<false>(a, nt, tiles, st);
   else e = (mma_dtype == FCVSR_BF16) ? dispatch<true>(a, nt, d0.kh, mw, wd, tiles, st) : dispatch<false>(a, nt, d0.kh, mw, wd, tiles, st);
   if (e != hipSuccess) {

@@ -1,0 +1,369 @@
+// 3x3 implicit-GEMM convolution with LDS-RESIDENT weights for the 64 / 128-channel layers that carry the FLOPs of the path
+// (BlockRCB / RCB bodies, conv_KP, F.0, group convs, recorb0, conv3: reference CVSR_freq.py:705-803, :1409-1416, :1430, :2608).
+//
+// conv3_lean_kernel (conv_mfma.hip) re-stages the 72 KiB weight block through LDS for every 4 x 32 pixel tile, tap by tap behind
+// two barriers per tap, and a wave owns 1 x 2 MFMA fragments (1.5 ds_read_b128 per MFMA): counting the weight re-staging the
+// LDS pipe is oversubscribed, which is what held it at 30 % of the MFMA roof.  Here:
+//   * persistent workgroups, one per CU (512 threads = 8 waves, two per SIMD); the 9 taps x 64 cin x 64 cout weight block
+//     (73,728 bytes, or 2 cin chunks x 9 taps x 32 couts for the 128-input-channel layers) is copied into LDS ONCE per workgroup;
+//   * the workgroup walks 8 x 32 pixel tiles.  Its two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) alternate roles
+//     every phase: one group multiplies its tile (2 rows x all couts per wave = 2 x 2 fragments, 1.0 ds_read_b128 per MFMA)
+//     while the other stores its previous tile straight from the accumulators and copies its next 10 x 34 halo tile into its
+//     own LDS buffer by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write).  ONE barrier per phase;
+//   * operand roles are swapped (weights = MFMA A operand, pixels = B operand), so a lane ends up with 4 consecutive output
+//     channels of ONE pixel per accumulator quad; a v_permlane32_swap pairs the quads of the two half-waves into 8 consecutive
+//     channels = one 16-byte store (16-bit destination).  No LDS transpose, hence no epilogue barrier and no epilogue LDS;
+//   * LDS-DMA writes 64 lanes x 16 bytes linearly, so rows cannot be padded: bank conflicts are avoided by an XOR swizzle on the
+//     per-lane SOURCE address (16-byte chunk c of halo column hx lands in slot c ^ ((hx >> 1) & 7); weights: by cout), which
+//     makes the 16 lanes of every ds_read_b128 phase hit 16 distinct 16-byte bank groups;
+//   * the 32 workgroups of one XCD (blockIdx % 8) share a contiguous range of tiles, so halo rows and both cout blocks of a
+//     tile hit in that XCD's L2.
+// LDS: 73,728 (weights) + 2 x 44,032 (halo tiles) + 256 (bias) = 162,048 of 163,840 bytes.
+#include <stdlib.h>
+#include "conv_res.h"
+#include "mfma_util.h"
+
+namespace fcvsr {
+
+constexpr int kRTH = 8, kRTW = 32, kRHW = kRTW + 2, kRHH = kRTH + 2;
+constexpr int kRNHP = kRHH * kRHW;                 // 340 halo pixels of 64 channels = 128 bytes each
+constexpr int kRNG = (kRNHP + 7) / 8;              // 43 LDS-DMA wave-instructions (8 pixels = 1 KiB each)
+constexpr int kRXBytes = kRNG * 1024;              // 44,032
+constexpr int kRWRows = 576;                       // weight rows of 64 cin (128 bytes)
+constexpr int kRWBytes = kRWRows * 128;            // 73,728
+constexpr int kRRowB = kRHW * 128;                 // bytes per halo row
+constexpr size_t kRLds = (size_t)kRWBytes + 2 * kRXBytes + 256;   // + 64 bias floats
+
+struct ResTile {
+  int gi, b, ty0, tx0;
+};
+
+__device__ __forceinline__ ResTile res_decode(const ResArgs& a, int tile) {
+  ResTile t;
+  t.gi = 0;
+  if (a.n_groups > 1 && tile >= a.g[1].tile_begin) t.gi = 1;
+  if (a.n_groups > 2 && tile >= a.g[2].tile_begin) t.gi = 2;
+  const ResGroup& G = a.g[t.gi];
+  const int tl = tile - G.tile_begin;
+  const int per_img = G.tiles_x * G.tiles_y;
+  t.b = tl / per_img;
+  const int t2 = tl - t.b * per_img;
+  const int ty = t2 / G.tiles_x;
+  t.ty0 = ty * kRTH;
+  t.tx0 = (t2 - ty * G.tiles_x) * kRTW;
+  return t;
+}
+
+// One LDS-DMA wave-instruction: lane l copies 16 bytes from its own global address to LDS byte (lds_off + 16 l).
+// Inline asm on purpose: with the builtin the compiler orders every later LDS read behind the copy (vmcnt(0)), which would
+// serialise the copy of the next tile with the multiplication of the current one.  The kernel waits for its copies itself.
+__device__ __forceinline__ void glds16(const void* src, unsigned lds_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(lds_off) : "memory");
+}
+
+// global -> LDS copy of the 64-channel chunk `ch` of a halo tile by the 4 waves of one group (wq = 0..3), 10-11 wave-instructions
+// each.  Offsets are 32-bit (the dispatcher checks that every source spans < 2^29 elements).
+__device__ __forceinline__ void res_stage(const ResArgs& a, const ResTile& t, int ch, unsigned xoff, int wq, int lane) {
+  const ResGroup& G = a.g[t.gi];
+  const char* sbase = reinterpret_cast<const char*>(G.src.p) + ((long long)t.b * G.src.sb + ch * 64) * 2;
+  const int sy2 = (int)G.src.sy * 2, sx2 = (int)G.src.sx * 2;
+  const int H = G.H, W = G.W;
+  const int tile_off = (t.ty0 - 1) * sy2 + (t.tx0 - 1) * sx2;          // wave-uniform
+  const int sub = lane >> 3, cl = lane & 7;
+#pragma unroll
+  for (int i = 0; i < (kRNG + 3) / 4; ++i) {
+    const int g = wq + 4 * i;
+    if (g < kRNG) {
+      const int p = g * 8 + sub;
+      const int hy = __mul24(p, 241) >> 13;         // p / 34 for p < 344
+      const int hx = p - __mul24(hy, kRHW);
+      const int iy = t.ty0 - 1 + hy, ix = t.tx0 - 1 + hx;
+      const int c = cl ^ ((hx >> 1) & 7);
+      const bool ok = (p < kRNHP) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+      const int off = tile_off + __mul24(hy, sy2) + __mul24(hx, sx2) + c * 16;
+      const char* src = ok ? sbase + off : reinterpret_cast<const char*>(a.zeros);
+      glds16(src, __builtin_amdgcn_readfirstlane(xoff + g * 1024));
+    }
+  }
+}
+
+// NCH = input-channel chunks of 64 (1 or 2); a workgroup owns CO = 64 / NCH output channels of every tile it visits.
+template <bool BF16, bool DST16, int NCH>
+__global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResArgs a) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  constexpr int CO = 64 / NCH;                       // couts per workgroup
+  constexpr int MF = CO / 32;                        // weight (A operand) fragments per wave
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: tile decoding and role branches stay on the SALU
+  const int r = lane & 31, h = lane >> 5;
+  const int grp = wave >> 2, wq = wave & 3;          // role group (0: waves 0-3, 1: waves 4-7), row pair inside the tile
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+
+  // ---- schedule: the workgroups of one XCD (blockIdx % 8) share a contiguous range of tiles; NB cout blocks per tile ------
+  const int NB = a.cout / CO;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int nb = loc % NB, slot = loc / NB, nslots = (gridDim.x >> 3) / NB;
+  const int tb = (int)((long long)xcd * a.total_tiles / 8), te = (int)((long long)(xcd + 1) * a.total_tiles / 8);
+  const int n0 = nb * CO;
+  const int ntile = (tb + slot < te) ? (te - tb - slot + nslots - 1) / nslots : 0;     // tiles of this workgroup
+  if (ntile == 0) return;                                                               // uniform per workgroup
+  const int nmine = (ntile - grp + 1) >> 1;          // tiles of my group: list indices grp, grp + 2, ...
+  const int NU = nmine * NCH;                        // my units (tile, chunk)
+  const int plast = 2 * ((ntile + 1) >> 1) * NCH;    // last phase (group 0's final epilogue / group 1's last compute + 1)
+
+  // ---- resident weights: rows [(ch*9 + tap) * CO + co] of 64 cin, chunk c of a row in slot c ^ ((co >> 1) & 7) -----------
+  {
+    const int sub = lane >> 3, cl = lane & 7;
+#pragma unroll
+    for (int i = 0; i < kRWRows / 8 / 8; ++i) {
+      const int g = wave + 8 * i;
+      const int row = g * 8 + sub;
+      const int q = row / CO, co = row - q * CO;     // CO is a power of two
+      const int ch = q / 9, tap = q - ch * 9;
+      const int c = cl ^ ((co >> 1) & 7);
+      const uint16_t* src = a.w + ((long long)tap * a.cout_pad + n0 + co) * a.cin_pad + ch * 64 + c * 8;
+      glds16(src, __builtin_amdgcn_readfirstlane(lds0 + g * 1024));
+    }
+  }
+  if (tid < CO) reinterpret_cast<float*>(lds + kRWBytes + 2 * kRXBytes)[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
+  const unsigned xoff = lds0 + kRWBytes + grp * kRXBytes;                // my group's halo buffer
+  if (grp == 0 && !(a.dbg & 1)) res_stage(a, res_decode(a, tb + slot), 0, xoff, wq, lane);
+
+  // Activation as max(x, 0) + ns * min(x, 0) with ns = 0 (ReLU), slope (LeakyReLU / PReLU) or 1 (none): the same values as the
+  // branchy form, and no per-element scalar branch on `act` (hipcc does not unswitch it: 64 branches per tile row).
+  // The PReLU slope is read by an explicitly GLOBAL load: a flat_load (address space not provable) stays "pending" in the
+  // compiler's wait-count bookkeeping for the rest of the kernel and turns every counted lgkmcnt(N) of the multiply loop into
+  // lgkmcnt(0).
+  float ns = 1.f;
+  if (a.act == FCVSR_ACT_RELU) ns = 0.f;
+  else if (a.act == FCVSR_ACT_LEAKY) ns = a.slope;
+  else if (a.act == FCVSR_ACT_PRELU) ns = *reinterpret_cast<const __attribute__((address_space(1))) float*>(reinterpret_cast<uintptr_t>(a.slope_ptr));
+  const bool r16 = a.res16 != 0;
+
+  // ---- fragment addresses (LDS byte offsets relative to lds) ------------------------------------------------------------
+  unsigned wb[4], xb[3][4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    wb[kk] = r * 128 + (((2 * kk + h) ^ ((r >> 1) & 7)) << 4);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+      xb[kx][kk] = kRWBytes + grp * kRXBytes + (2 * wq * kRHW + r + kx) * 128 + (((2 * kk + h) ^ (((r + kx) >> 1) & 7)) << 4);
+  }
+
+  f32x16_t acc[MF][2];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                   // weights and group 0's first tile have landed
+
+  int k = 0;                                         // my next unit to multiply
+#pragma unroll 1
+  for (int p = 0;; ++p) {
+    if ((p & 1) == grp) {
+      // ================= multiply unit k: tile list index 2 * (k / NCH) + grp, chunk k % NCH ==========================
+      if (k < NU) {
+        const int ch = (NCH == 1) ? 0 : (k & (NCH - 1));
+        if (ch == 0) {
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int i = 0; i < 16; ++i) acc[mf][j][i] = 0.f;
+        }
+        if (!(a.dbg & 2)) {
+          __builtin_amdgcn_s_setprio(2);              // the multiplying wave wins VALU/MFMA issue over its SIMD partner's epilogue
+          const unsigned wch = ch * (9 * CO * 128);
+          uint4 wf[2][MF], xf[2][2];
+#define FCVSR_RES_LOAD(S, SLOT)                                                                                  \
+  do {                                                                                                           \
+    constexpr int tap_ = (S) / 4, kk_ = (S) % 4, ky_ = tap_ / 3, kx_ = tap_ % 3;                                 \
+    _Pragma("unroll") for (int mf = 0; mf < MF; ++mf)                                                            \
+        wf[SLOT][mf] = *reinterpret_cast<const uint4*>(lds + wb[kk_] + wch + (tap_ * CO + mf * 32) * 128);       \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
+        xf[SLOT][j] = *reinterpret_cast<const uint4*>(lds + xb[kx_][kk_] + (j + ky_) * kRRowB);                   \
+  } while (0)
+#define FCVSR_RES_STEP(S)                                                                                        \
+  do {                                                                                                           \
+    if ((S) + 1 < 36) FCVSR_RES_LOAD(((S) + 1) % 36, ((S) + 1) & 1);                                             \
+    _Pragma("unroll") for (int mf = 0; mf < MF; ++mf)                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+            acc[mf][j] = mfma<BF16>(wf[(S) & 1][mf], xf[(S) & 1][j], acc[mf][j]);                                 \
+    if ((S) + 1 < 36) __builtin_amdgcn_sched_group_barrier(0x100, MF + 2, 0);                                    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF, 0);                                                      \
+  } while (0)
+          FCVSR_RES_LOAD(0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          FCVSR_RES_STEP(0);  FCVSR_RES_STEP(1);  FCVSR_RES_STEP(2);  FCVSR_RES_STEP(3);  FCVSR_RES_STEP(4);  FCVSR_RES_STEP(5);
+          FCVSR_RES_STEP(6);  FCVSR_RES_STEP(7);  FCVSR_RES_STEP(8);  FCVSR_RES_STEP(9);  FCVSR_RES_STEP(10); FCVSR_RES_STEP(11);
+          FCVSR_RES_STEP(12); FCVSR_RES_STEP(13); FCVSR_RES_STEP(14); FCVSR_RES_STEP(15); FCVSR_RES_STEP(16); FCVSR_RES_STEP(17);
+          FCVSR_RES_STEP(18); FCVSR_RES_STEP(19); FCVSR_RES_STEP(20); FCVSR_RES_STEP(21); FCVSR_RES_STEP(22); FCVSR_RES_STEP(23);
+          FCVSR_RES_STEP(24); FCVSR_RES_STEP(25); FCVSR_RES_STEP(26); FCVSR_RES_STEP(27); FCVSR_RES_STEP(28); FCVSR_RES_STEP(29);
+          FCVSR_RES_STEP(30); FCVSR_RES_STEP(31); FCVSR_RES_STEP(32); FCVSR_RES_STEP(33); FCVSR_RES_STEP(34); FCVSR_RES_STEP(35);
+#undef FCVSR_RES_STEP
+#undef FCVSR_RES_LOAD
+          __builtin_amdgcn_s_setprio(0);
+        }
+      }
+      ++k;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS reads are complete before the other phase's copy overwrites
+    } else {
+      // ================= copy unit k into my buffer; store the tile whose last chunk was unit k - 1 =======================
+      if (k < NU && !(a.dbg & 1)) {
+        const int li = 2 * (k / NCH) + grp;
+        res_stage(a, res_decode(a, tb + slot + li * nslots), (NCH == 1) ? 0 : (k & (NCH - 1)), xoff, wq, lane);
+      }
+      int nst = 0;                                   // store wave-instructions issued below (wave-uniform)
+      if (k >= 1 && k <= NU && ((k - 1) & (NCH - 1)) == NCH - 1 && !(a.dbg & 8)) {
+        // Branch-free up to the stores: every load of a tile row (bias from LDS, residuals from HBM) is issued before the first
+        // use, so a row costs one memory round trip instead of one per 8-channel chunk.
+        const int li = 2 * ((k - 1) / NCH) + grp;
+        const ResTile t = res_decode(a, tb + slot + li * nslots);
+        const ResGroup& G = a.g[t.gi];
+        const View dv = G.dst, r0v = G.res[0], r1v = G.res[1];
+        const int px = t.tx0 + r;
+        const float* bias_s = reinterpret_cast<const float*>(lds + kRWBytes + 2 * kRXBytes) + 8 * h;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (j) __builtin_amdgcn_sched_barrier(0);    // one row at a time: hoisting both rows' loads spills
+          const int py = t.ty0 + 2 * wq + j;
+          const bool ok = (py < G.H) && (px < G.W) && !(a.dbg & 4);
+          // lanes outside the image read the residuals of the image's first pixel (always a valid address) and store nothing
+          const int pyc = ok ? py : 0, pxc = ok ? px : 0;
+          const long long dpix = (long long)t.b * dv.sb + (long long)pyc * dv.sy + (long long)pxc * dv.sx + n0 + 8 * h;
+          const long long r0pix = (long long)t.b * r0v.sb + (long long)pyc * r0v.sy + (long long)pxc * r0v.sx + n0 + 8 * h;
+          const long long r1pix = (long long)t.b * r1v.sb + (long long)pyc * r1v.sy + (long long)pxc * r1v.sx + n0 + 8 * h;
+          // accumulator quads 2q, 2q+1 of the two half-waves -> 8 consecutive couts mf*32 + 16q + 8h + [0, 8) of pixel r
+          float x[MF][2][8];
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const float4 b0 = *reinterpret_cast<const float4*>(bias_s + mf * 32 + 16 * q);
+              const float4 b1 = *reinterpret_cast<const float4*>(bias_s + mf * 32 + 16 * q + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                typedef __attribute__((ext_vector_type(2))) unsigned u2_t;
+                const u2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mf][j][8 * q + e]),
+                                                                 __float_as_uint(acc[mf][j][8 * q + 4 + e]), false, false);
+                x[mf][q][e] = __uint_as_float(sw.x);
+                x[mf][q][4 + e] = __uint_as_float(sw.y);
+              }
+              x[mf][q][0] += b0.x; x[mf][q][1] += b0.y; x[mf][q][2] += b0.z; x[mf][q][3] += b0.w;
+              x[mf][q][4] += b1.x; x[mf][q][5] += b1.y; x[mf][q][6] += b1.z; x[mf][q][7] += b1.w;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[mf][q][e] = fmaxf(x[mf][q][e], 0.f) + ns * fminf(x[mf][q][e], 0.f);
+            }
+#pragma unroll
+          for (int ri = 0; ri < 2; ++ri) {
+            if (ri < a.n_res) {
+              const float* rp = ri == 0 ? r0v.p : r1v.p;
+              const long long rpix = ri == 0 ? r0pix : r1pix;
+              const float rs = a.rs[ri];
+              if (r16) {
+                uint4 v[MF][2];
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                  for (int q = 0; q < 2; ++q)
+                    v[mf][q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(rp) + rpix + mf * 32 + 16 * q);
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                  for (int q = 0; q < 2; ++q) {
+                    float rr[8];
+                    cvt16x4_to_f32<BF16>(make_uint2(v[mf][q].x, v[mf][q].y), rr);
+                    cvt16x4_to_f32<BF16>(make_uint2(v[mf][q].z, v[mf][q].w), rr + 4);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[mf][q][e] = fmaf(rs, rr[e], x[mf][q][e]);
+                  }
+              } else {
+                float4 v[MF][2][2];
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                  for (int q = 0; q < 2; ++q) {
+                    v[mf][q][0] = *reinterpret_cast<const float4*>(rp + rpix + mf * 32 + 16 * q);
+                    v[mf][q][1] = *reinterpret_cast<const float4*>(rp + rpix + mf * 32 + 16 * q + 4);
+                  }
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                  for (int q = 0; q < 2; ++q) {
+                    const float4 u0 = v[mf][q][0], u1 = v[mf][q][1];
+                    x[mf][q][0] = fmaf(rs, u0.x, x[mf][q][0]); x[mf][q][1] = fmaf(rs, u0.y, x[mf][q][1]);
+                    x[mf][q][2] = fmaf(rs, u0.z, x[mf][q][2]); x[mf][q][3] = fmaf(rs, u0.w, x[mf][q][3]);
+                    x[mf][q][4] = fmaf(rs, u1.x, x[mf][q][4]); x[mf][q][5] = fmaf(rs, u1.y, x[mf][q][5]);
+                    x[mf][q][6] = fmaf(rs, u1.z, x[mf][q][6]); x[mf][q][7] = fmaf(rs, u1.w, x[mf][q][7]);
+                  }
+              }
+            }
+          }
+          if (__builtin_amdgcn_ballot_w64(ok) != 0) nst += MF * 2 * (DST16 ? 1 : 2);   // the block below runs iff some lane is live
+          if (ok) {
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                const float* xx = x[mf][q];
+                if (DST16) {
+                  const uint2 lo = cvt4<BF16>(make_float4(xx[0], xx[1], xx[2], xx[3])), hi = cvt4<BF16>(make_float4(xx[4], xx[5], xx[6], xx[7]));
+                  *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(dv.p) + dpix + mf * 32 + 16 * q) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                } else {
+                  *reinterpret_cast<float4*>(dv.p + dpix + mf * 32 + 16 * q) = make_float4(xx[0], xx[1], xx[2], xx[3]);
+                  *reinterpret_cast<float4*>(dv.p + dpix + mf * 32 + 16 * q + 4) = make_float4(xx[4], xx[5], xx[6], xx[7]);
+                }
+              }
+          }
+        }
+      }
+      // My copies must have landed before the barrier; my stores need not have.  vmcnt counts loads, LDS-DMA and stores
+      // together in issue order, and the stores are the youngest operations: leave exactly them outstanding (waiting for them
+      // too exposes a full HBM write round trip per phase - measured 78 vs 54 us on a 64->64 layer).
+      constexpr int SR = MF * 2 * (DST16 ? 1 : 2);   // stores per tile row
+      if (nst == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (nst == SR) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SR) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SR) : "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (p >= plast) break;
+  }
+}
+
+bool conv3_res_supports(int cin, int cout) { return (cin == 64 && cout % 64 == 0) || (cin == 128 && cout % 32 == 0); }
+
+template <bool BF16, bool DST16, int NCH>
+static hipError_t launch_res(const ResArgs& a, hipStream_t st) {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)conv3_res_kernel<BF16, DST16, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRLds);
+    if (e != hipSuccess) return e;
+    n_cu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
+  }
+  const int NB = a.cout / (64 / NCH);
+  // one persistent workgroup per CU; the grid is a multiple of 8 * NB (every XCD gets whole slots of NB cout blocks)
+  int grid = n_cu / (8 * NB) * (8 * NB);
+  if (grid < 8 * NB) grid = 8 * NB;
+  const int need = (a.total_tiles + 7) / 8 * 8 * NB;
+  if (grid > need) grid = need;
+  hipLaunchKernelGGL((conv3_res_kernel<BF16, DST16, NCH>), dim3(grid), dim3(512), kRLds, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv3_res(const ResArgs& a, bool bf16, bool dst16, hipStream_t st) {
+  if (!conv3_res_supports(a.cin, a.cout)) return hipErrorInvalidValue;
+  if (a.cin == 64) {
+    if (bf16) return dst16 ? launch_res<true, true, 1>(a, st) : launch_res<true, false, 1>(a, st);
+    return dst16 ? launch_res<false, true, 1>(a, st) : launch_res<false, false, 1>(a, st);
+  }
+  if (bf16) return dst16 ? launch_res<true, true, 2>(a, st) : launch_res<true, false, 2>(a, st);
+  return dst16 ? launch_res<false, true, 2>(a, st) : launch_res<false, false, 2>(a, st);
+}
+
+}  // namespace fcvsr

@@ -1,4 +1,4 @@
-// Small device helpers shared by the MFMA convolution kernels (conv_mfma.hip, conv_ws.hip).
+// Small device helpers shared by the MFMA convolution kernels (conv_mfma.hip, conv_res.hip).
 #pragma once
 #include "common.h"
 

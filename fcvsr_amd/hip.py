@@ -66,6 +66,7 @@ _VP, _I, _I64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _PV = C.POINTER(View)
 SIGNATURES = {
     "fcvsr_last_error": [],
+    "fcvsr_last_conv_kernel": [],
     "fcvsr_abi_version": [],
     "fcvsr_device_count": [],
     "fcvsr_conv2d": [C.POINTER(ConvDesc), _VP],
@@ -100,7 +101,7 @@ SIGNATURES = {
     "fcvsr_bilinear_up4": [_PV, _I, _I, _I, _PV, _VP],
     "fcvsr_tail_fused": [_PV, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _PV, _VP],
 }
-_RESTYPES = {"fcvsr_last_error": C.c_char_p}
+_RESTYPES = {"fcvsr_last_error": C.c_char_p, "fcvsr_last_conv_kernel": C.c_char_p}
 
 
 def lib() -> C.CDLL:
@@ -237,13 +238,9 @@ def conv2d_mfma(groups, wpacked: torch.Tensor, ksize: int, cout: int, mma_dtype:
         check(lib().fcvsr_conv2d_mfma(descs, n, mma_dtype, stream_ptr()), "fcvsr_conv2d_mfma")
         e1.record()
         nbytes = sum(t.numel() * t.element_size() for g in groups for t in list(g["srcs"]) + list(g.get("res", ())) + [g["dst"]])
-        # which kernel the dispatcher picks for the layers that dominate the run (see fcvsr_conv2d_mfma): the lean 3x3
-        # kernel with 16-bit source and destination = conv3_lean_kernel<BF16, 64, true, true>
-        g0 = groups[0]
-        lean16 = (ksize == 3 and stride == 1 and len(g0["srcs"]) == 1 and not pixel_shuffle and gc_wmask is None
-                  and g0["srcs"][0].dtype != torch.float32 and g0["dst"].dtype != torch.float32
-                  and g0["srcs"][0].shape[-1] % 64 == 0 and cout > 32)
-        PROFILE.append((e0, e1, flops, "mfma", name, nbytes, "conv3_lean16" if lean16 else "other"))
+        # the kernel the dispatcher actually launched (fcvsr_last_conv_kernel): bench.py groups the timings by it
+        kname = lib().fcvsr_last_conv_kernel().decode()
+        PROFILE.append((e0, e1, flops, "mfma", name, nbytes, kname))
         return
     check(lib().fcvsr_conv2d_mfma(descs, n, mma_dtype, stream_ptr()), "fcvsr_conv2d_mfma")
 

@@ -88,6 +88,9 @@ int fcvsr_conv2d(const fcvsr_conv_desc* d, void* stream);
  * With pixel_shuffle the weight/bias rows must be ordered sub-pixel-major: row (2*i+j)*(cout/4)+c holds original output
  * channel 4*c+2*i+j, so that one lane's 4 consecutive couts land in one pixel of the shuffled output. */
 int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int mma_dtype, void* stream);
+/* Name (template instance) of the kernel the calling thread's last fcvsr_conv2d_mfma call launched, e.g.
+ * "conv3_res_kernel<true, true, 1>": measurement aid for bench.py's per-kernel roofline, not part of the data path. */
+const char* fcvsr_last_conv_kernel(void);
 
 /* ---- frequency transforms: torch.fft.rfft2 / irfft2 (norm='backward') of NHWC channel groups -------------
  * Spectrum layout: buffer [B][H][Wf][pix_stride] with Wf=W/2+1; channel c of the group has its imaginary part at

@@ -1,4 +1,4 @@
-"""Weight-stationary 3x3 kernel vs the lean kernel: exactness (same accumulation order -> bit-identical) and speed."""
+"""LDS-resident-weight 3x3 kernel (conv_res.hip) vs the lean kernel: exactness (same accumulation order -> bit-identical) and speed."""
 import os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import torch
@@ -33,23 +33,25 @@ def main():
     import inspect
     print(inspect.signature(hip.conv2d_mfma))
     for cin, cout, B, levels, d16, nres in ((64, 64, 2, [(21, 37)], True, 0), (64, 64, 2, [(21, 37), (11, 19), (6, 10)], False, 2),
-                                            (64, 128, 1, [(40, 70)], True, 1), (64, 256, 1, [(17, 33)], True, 0)):
+                                            (64, 128, 1, [(40, 70)], True, 1), (64, 256, 1, [(17, 33)], True, 0),
+                                            (128, 64, 2, [(40, 70), (20, 35)], True, 1)):
         wp, bias, groups, _ = make(cin, cout, B, levels, d16, nres)
-        os.environ["FCVSR_MFMA_WS"] = "0"; run(groups, wp, bias, cout, nres); torch.cuda.synchronize()
+        os.environ["FCVSR_MFMA_RES"] = "0"; run(groups, wp, bias, cout, nres); torch.cuda.synchronize()
         ref = [g["dst"].clone() for g in groups]
         for g in groups: g["dst"].zero_()
-        os.environ["FCVSR_MFMA_WS"] = "1"; run(groups, wp, bias, cout, nres); torch.cuda.synchronize()
+        os.environ["FCVSR_MFMA_RES"] = "1"; run(groups, wp, bias, cout, nres); torch.cuda.synchronize()
         err = max(float((g["dst"].float() - r.float()).abs().max()) for g, r in zip(groups, ref))
-        print(f"exactness {cin}->{cout} B={B} levels={levels} d16={d16} nres={nres}: max |ws - lean| = {err:g}", flush=True)
+        print(f"exactness {cin}->{cout} B={B} levels={levels} d16={d16} nres={nres}: max |res - lean| = {err:g}", flush=True)
     
     for cin, cout, B, levels, d16 in ((64, 64, 4, L3[:1], True), (64, 64, 16, L3[:1], True), (64, 64, 16, L3, True), (64, 64, 16, L3, False),
-                                      (64, 128, 4, L3, True), (64, 128, 16, L3, True), (64, 256, 8, L3[:1], True)):
+                                      (64, 128, 4, L3, True), (64, 128, 16, L3, True), (64, 256, 8, L3[:1], True),
+                                      (128, 64, 4, L3, True), (128, 64, 16, L3, True)):
         wp, bias, groups, flops = make(cin, cout, B, levels, d16, 0)
         out = []
         for ws in ("0", "1"):
-            os.environ["FCVSR_MFMA_WS"] = ws
+            os.environ["FCVSR_MFMA_RES"] = ws
             us = timeit(lambda: run(groups, wp, bias, cout, 0))
-            out.append(f"{'ws' if ws == '1' else 'lean'} {us:8.1f} us {flops/us/1e6:7.1f} TF/s")
+            out.append(f"{'res' if ws == '1' else 'lean'} {us:8.1f} us {flops/us/1e6:7.1f} TF/s")
         print(f"{cin}->{cout} B={B} levels={len(levels)} d16={d16}: " + " | ".join(out), flush=True)
 
 if __name__ == '__main__':

@@ -290,32 +290,38 @@ def test_flow_warp_known_answer():
     assert float((nchw(out) - ref).abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize("cout,d16,nres,levels", [(64, True, 0, [(21, 37)]), (64, False, 2, [(21, 37), (11, 19), (6, 10)]),
-                                                  (128, True, 1, [(20, 70)]), (256, True, 0, [(9, 33)])])
-def test_conv_weight_stationary_matches_lean(cout, d16, nres, levels, monkeypatch):
-    """The opt-in weight-stationary 3x3 kernel (FCVSR_MFMA_WS=1, conv_ws.hip) accumulates in the same order as the lean
-    kernel, so the two must agree bit for bit (partial tiles, three grouped levels, residuals, both destination types)."""
+@pytest.mark.parametrize("cin,cout,d16,nres,levels", [(64, 64, True, 0, [(21, 37)]), (64, 64, False, 2, [(21, 37), (11, 19), (6, 10)]),
+                                                      (64, 128, True, 1, [(20, 70)]), (64, 256, True, 0, [(9, 33)]),
+                                                      (128, 64, True, 1, [(21, 37), (11, 19)]), (128, 64, False, 0, [(16, 64)]),
+                                                      (64, 64, True, 2, [(180, 320), (90, 160), (45, 80)])])
+def test_conv_resident_weights_matches_lean(cin, cout, d16, nres, levels, monkeypatch):
+    """The LDS-resident-weight 3x3 kernel (conv_res.hip; FCVSR_MFMA_RES=1 forces it at any size) accumulates the 16-deep
+    k-steps in the same order as the lean kernel, so the two must agree bit for bit (partial tiles, three grouped levels,
+    residuals, both destination types, both input-channel counts, odd tile counts per workgroup)."""
     from fcvsr_amd import hip
     dt = torch.bfloat16
-    g0 = torch.Generator().manual_seed(cout + nres)
-    w = torch.randn(cout, 64, 3, 3, generator=g0) / 24.0
+    g0 = torch.Generator().manual_seed(cout + nres + cin)
+    w = torch.randn(cout, cin, 3, 3, generator=g0) / (3.0 * cin ** 0.5)
     bias = torch.randn(cout, generator=g0).cuda()
     wp = hip.pack_conv_weight_mfma(w.cuda(), dt)
     groups = []
+    B = 2 if levels[0][0] < 100 else 3
     for (H, W) in levels:
-        x = torch.randn(2, H, W, 64, generator=g0).cuda().to(dt)
-        y = torch.empty(2, H, W, cout, device="cuda", dtype=dt if d16 else torch.float32)
-        res = [torch.randn(2, H, W, cout, generator=g0).cuda().to(dt) for _ in range(nres)]
+        x = torch.randn(B, H, W, cin, generator=g0).cuda().to(dt)
+        y = torch.empty(B, H, W, cout, device="cuda", dtype=dt if d16 else torch.float32)
+        res = [torch.randn(B, H, W, cout, generator=g0).cuda().to(dt) for _ in range(nres)]
         groups.append(dict(srcs=[x], dst=y, res=res))
     outs = []
-    for ws in ("0", "1"):
-        monkeypatch.setenv("FCVSR_MFMA_WS", ws)
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FCVSR_MFMA_RES", mode)
         for g in groups:
-            g["dst"].zero_()
+            g["dst"].fill_(float("nan"))
         hip.conv2d_mfma(groups, wp, 3, cout, hip.BF16, bias=bias, act=hip.ACT_LEAKY, slope=0.1, res_scale=[1.0, -0.5][:nres])
         torch.cuda.synchronize()
         outs.append([g["dst"].clone() for g in groups])
+    monkeypatch.delenv("FCVSR_MFMA_RES")
     for a, b in zip(*outs):
+        assert not torch.isnan(a.float()).any() and not torch.isnan(b.float()).any()
         assert torch.equal(a, b)
 
 

@@ -1172,6 +1172,14 @@ static hipError_t dispatch(const MfmaArgs& a, int nt, int ks, int mw, int wd, in
 
 using namespace fcvsr;
 
+// diagnostic stamp buffer of the resident-weight kernel (FCVSR_RES_STAMPS=1): [wave 8][phase 64][slot 8] u64
+static void* g_res_stamps = nullptr;
+static const size_t kResStampBytes = 8 * 64 * 8 * sizeof(unsigned long long);
+extern "C" int fcvsr_debug_res_stamps(void* host_out, size_t bytes) {
+  if (!g_res_stamps || bytes > kResStampBytes) return FCVSR_E_ARG;
+  return (int)hipMemcpy(host_out, g_res_stamps, bytes, hipMemcpyDeviceToHost);
+}
+
 // name of the kernel the last fcvsr_conv2d_mfma call of this thread launched (bench.py groups its per-launch timings by it)
 static thread_local char g_last_kernel[96] = "";
 extern "C" const char* fcvsr_last_conv_kernel(void) { return g_last_kernel; }
@@ -1416,7 +1424,16 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
     wa.w = a.w; wa.bias = a.bias; wa.act = a.act; wa.slope = a.slope; wa.slope_ptr = a.slope_ptr;
     wa.rs[0] = a.rs[0]; wa.rs[1] = a.rs[1]; wa.n_res = a.n_res; wa.res16 = a.res16; wa.zeros = zeros;
     { const char* wd_ = getenv("FCVSR_RES_DBG"); wa.dbg = wd_ ? atoi(wd_) : 0; }
-    FCVSR_NOTE_KERNEL("conv3_res_kernel<%s, %s, %d>", tf(mma_dtype == FCVSR_BF16), tf(a.dst16), cin / 64);
+    wa.stamps = nullptr;
+    {
+      const char* ws_ = getenv("FCVSR_RES_STAMPS");       // diagnostic: in-kernel cycle stamps of one workgroup (scripts/res_stamps.py)
+      if (ws_ && atoi(ws_)) {
+        if (!g_res_stamps && hipMalloc(&g_res_stamps, kResStampBytes) != hipSuccess) g_res_stamps = nullptr;
+        if (g_res_stamps) (void)hipMemsetAsync(g_res_stamps, 0, kResStampBytes, st);
+        wa.stamps = (unsigned long long*)g_res_stamps;
+      }
+    }
+    FCVSR_NOTE_KERNEL("conv3_res_kernel<%s, %d, %d>", tf(mma_dtype == FCVSR_BF16), !a.dst16 ? 0 : (a.n_res == 0 ? 2 : 1), cin / 64);
     e = launch_conv3_res(wa, mma_dtype == FCVSR_BF16, a.dst16 != 0, st);
     if (e != hipSuccess) {
       set_error("fcvsr_conv2d_mfma: resident-weight launch failed: %s", hipGetErrorString(e));

@@ -26,6 +26,7 @@ struct ResArgs {
   int n_res, res16;
   const void* zeros;      // >= 16 zero bytes: source of the halo pixels that lie outside the image
   int dbg;                // profiling ablations (FCVSR_RES_DBG): 1 skip staging, 2 skip MFMA, 4 skip stores
+  unsigned long long* stamps;   // diagnostic (FCVSR_RES_STAMPS=1): s_memtime stamps of workgroup 0, [wave 8][phase 64][slot 8]; else nullptr
 };
 
 // returns hipSuccess, or hipErrorInvalidValue when the shape is not one the kernel is built for

@@ -18,8 +18,9 @@
 //     makes the 16 lanes of every ds_read_b128 phase hit 16 distinct 16-byte bank groups;
 //   * the 32 workgroups of one XCD (blockIdx % 8) share a contiguous range of tiles, so halo rows and both cout blocks of a
 //     tile hit in that XCD's L2.
-// LDS: 73,728 (weights) + 2 x 44,032 (halo tiles) + 256 (bias) = 162,048 of 163,840 bytes.
+// LDS: 73,728 (weights) + 2 x 44,032 (halo tiles) + 256 (bias) + 384 (group parameters) = 162,432 of 163,840 bytes.
 #include <stdlib.h>
+#include <type_traits>
 #include "conv_res.h"
 #include "mfma_util.h"
 
@@ -32,26 +33,57 @@ constexpr int kRXBytes = kRNG * 1024;              // 44,032
 constexpr int kRWRows = 576;                       // weight rows of 64 cin (128 bytes)
 constexpr int kRWBytes = kRWRows * 128;            // 73,728
 constexpr int kRRowB = kRHW * 128;                 // bytes per halo row
-constexpr size_t kRLds = (size_t)kRWBytes + 2 * kRXBytes + 256;   // + 64 bias floats
+constexpr int kRBiasOff = kRWBytes + 2 * kRXBytes;  // 64 bias floats
+constexpr int kRTabOff = kRBiasOff + 256;           // per-group parameter table: 3 x 32 dwords
+constexpr size_t kRLds = (size_t)kRTabOff + 3 * 32 * 4;
+
+// Per-group parameters as 32-bit words.  The kernel reads them from LDS: indexing the kernel-argument block by a run-time group
+// index makes hipcc fetch it with VECTOR loads, whose s_waitcnt vmcnt(0) also waits for the stores of the previous tile that the
+// storing role leaves in flight on purpose (measured: 5-6 k of a 9 k-cycle phase).  Offsets are 32-bit: the dispatcher checks
+// that every tensor spans < 2^29 elements.
+enum {
+  kTSrcLo = 0, kTSrcHi, kTSrcSb2, kTSrcSy2, kTSrcSx2, kTH, kTW, kTTilesX, kTPerImg, kTTileBegin,
+  kTDstLo = 12, kTDstHi, kTDstSb, kTDstSy, kTDstSx, kTR0Lo, kTR0Hi, kTR0Sb, kTR0Sy, kTR0Sx, kTR1Lo, kTR1Hi, kTR1Sb, kTR1Sy, kTR1Sx
+};
+
+struct ResK {                                        // kernel arguments
+  int n_groups, total_tiles, cout, cout_pad, cin_pad, act, n_res, res16, dbg;
+  float slope, rs[2];
+  const float* slope_ptr;
+  const uint16_t* w;
+  const float* bias;
+  const void* zeros;
+  unsigned long long* stamps;
+  int tab[3][32];
+};
 
 struct ResTile {
   int gi, b, ty0, tx0;
 };
 
-__device__ __forceinline__ ResTile res_decode(const ResArgs& a, int tile) {
+__device__ __forceinline__ ResTile res_decode(const int* tabL, int n_groups, int tile) {
   ResTile t;
   t.gi = 0;
-  if (a.n_groups > 1 && tile >= a.g[1].tile_begin) t.gi = 1;
-  if (a.n_groups > 2 && tile >= a.g[2].tile_begin) t.gi = 2;
-  const ResGroup& G = a.g[t.gi];
-  const int tl = tile - G.tile_begin;
-  const int per_img = G.tiles_x * G.tiles_y;
+  if (n_groups > 1 && tile >= tabL[32 + kTTileBegin]) t.gi = 1;
+  if (n_groups > 2 && tile >= tabL[64 + kTTileBegin]) t.gi = 2;
+  const int* T = tabL + t.gi * 32;
+  const int tl = tile - T[kTTileBegin];
+  const int per_img = T[kTPerImg], tiles_x = T[kTTilesX];
   t.b = tl / per_img;
   const int t2 = tl - t.b * per_img;
-  const int ty = t2 / G.tiles_x;
+  const int ty = t2 / tiles_x;
   t.ty0 = ty * kRTH;
-  t.tx0 = (t2 - ty * G.tiles_x) * kRTW;
+  t.tx0 = (t2 - ty * tiles_x) * kRTW;
   return t;
+}
+
+// Pointers rebuilt from table words are declared GLOBAL (address space 1): a generic pointer makes hipcc emit flat_load /
+// flat_store, which count on lgkmcnt as well and turn every counted LDS wait of the multiply loop into lgkmcnt(0).
+typedef __attribute__((address_space(1))) char gchar_t;
+typedef __attribute__((address_space(1))) uint4 guint4_t;
+typedef __attribute__((address_space(1))) float4 gfloat4_t;
+__device__ __forceinline__ gchar_t* tab_ptr(const int* T, int lo) {
+  return reinterpret_cast<gchar_t*>(((unsigned long long)(unsigned)T[lo + 1] << 32) | (unsigned)T[lo]);
 }
 
 // One LDS-DMA wave-instruction: lane l copies 16 bytes from its own global address to LDS byte (lds_off + 16 l).
@@ -64,34 +96,47 @@ __device__ __forceinline__ void glds16(const void* src, unsigned lds_off) {
 }
 
 // global -> LDS copy of the 64-channel chunk `ch` of a halo tile by the 4 waves of one group (wq = 0..3), 10-11 wave-instructions
-// each.  Offsets are 32-bit (the dispatcher checks that every source spans < 2^29 elements).
-__device__ __forceinline__ void res_stage(const ResArgs& a, const ResTile& t, int ch, unsigned xoff, int wq, int lane) {
-  const ResGroup& G = a.g[t.gi];
-  const char* sbase = reinterpret_cast<const char*>(G.src.p) + ((long long)t.b * G.src.sb + ch * 64) * 2;
-  const int sy2 = (int)G.src.sy * 2, sx2 = (int)G.src.sx * 2;
-  const int H = G.H, W = G.W;
-  const int tile_off = (t.ty0 - 1) * sy2 + (t.tx0 - 1) * sx2;          // wave-uniform
+// each, straight-line (halo pixels outside the image, and the 4 pixels past the tile in the last instruction, read the zero page).
+__device__ __forceinline__ void res_stage(const int* tabL, const void* zeros, const ResTile& t, int ch, unsigned xoff, int wq, int lane) {
+  const int* T = tabL + t.gi * 32;
+  const char* sbase = (const char*)(tab_ptr(T, kTSrcLo) + (long long)t.b * T[kTSrcSb2] + ch * 128);
+  const int sy2 = T[kTSrcSy2], sx2 = T[kTSrcSx2];
+  const int H = T[kTH], W = T[kTW];
   const int sub = lane >> 3, cl = lane & 7;
 #pragma unroll
   for (int i = 0; i < (kRNG + 3) / 4; ++i) {
     const int g = wq + 4 * i;
-    if (g < kRNG) {
+    if (i * 4 + 3 < kRNG || g < kRNG) {              // only the last round (i = 10) has a (wave-uniform) condition
       const int p = g * 8 + sub;
       const int hy = __mul24(p, 241) >> 13;         // p / 34 for p < 344
       const int hx = p - __mul24(hy, kRHW);
       const int iy = t.ty0 - 1 + hy, ix = t.tx0 - 1 + hx;
       const int c = cl ^ ((hx >> 1) & 7);
       const bool ok = (p < kRNHP) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
-      const int off = tile_off + __mul24(hy, sy2) + __mul24(hx, sx2) + c * 16;
-      const char* src = ok ? sbase + off : reinterpret_cast<const char*>(a.zeros);
+      const int off = __mul24(iy, sy2) + __mul24(ix, sx2) + c * 16;
+      const char* src = ok ? sbase + off : reinterpret_cast<const char*>(zeros);
       glds16(src, __builtin_amdgcn_readfirstlane(xoff + g * 1024));
     }
   }
 }
 
+// Diagnostic build switch only (a.stamps != nullptr): in-kernel cycle stamps of one workgroup, written to a buffer nothing else
+// reads (scripts/res_stamps.py prints where a phase spends its cycles).  No stamp executes in the normal path.
+#define FCVSR_RES_STAMP(SLOT)                                                                                          \
+  do {                                                                                                                 \
+    if (a.stamps && blockIdx.x == 8 && p < 64 && lane == 0)                                                            \
+      a.stamps[(wave * 64 + p) * 8 + (SLOT)] = __builtin_amdgcn_s_memtime();                                           \
+  } while (0)
+
 // NCH = input-channel chunks of 64 (1 or 2); a workgroup owns CO = 64 / NCH output channels of every tile it visits.
-template <bool BF16, bool DST16, int NCH>
-__global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResArgs a) {
+// MODE: 0 = f32 destination, 1 = 16-bit destination, 2 = 16-bit destination without residuals (the multiplying wave packs).
+// NSU: the activation's negative-side factor lies in [0, 1] (ReLU, LeakyReLU, none): act(x) = max(x, ns * x).
+// Both are template parameters because hipcc re-merges wave-uniform run-time variants into one body with a scalar branch
+// per 4 values (SimplifyCFG hoists the common code of the arms): ~40 branches per tile in the epilogue.
+template <bool BF16, int MODE, int NCH, bool NSU>
+__global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResK a) {
+  constexpr bool DST16 = MODE != 0;
+  constexpr bool FAST = MODE == 2;
   extern __shared__ __align__(16) unsigned char lds[];
   constexpr int CO = 64 / NCH;                       // couts per workgroup
   constexpr int MF = CO / 32;                        // weight (A operand) fragments per wave
@@ -127,11 +172,15 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResArgs a) {
       glds16(src, __builtin_amdgcn_readfirstlane(lds0 + g * 1024));
     }
   }
-  if (tid < CO) reinterpret_cast<float*>(lds + kRWBytes + 2 * kRXBytes)[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
+  if (tid < CO) reinterpret_cast<float*>(lds + kRBiasOff)[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
+  if (tid >= 128 && tid < 128 + 96) reinterpret_cast<int*>(lds + kRTabOff)[tid - 128] = a.tab[(tid - 128) >> 5][(tid - 128) & 31];
+  const int* tabL = reinterpret_cast<const int*>(lds + kRTabOff);
   const unsigned xoff = lds0 + kRWBytes + grp * kRXBytes;                // my group's halo buffer
-  if (grp == 0 && !(a.dbg & 1)) res_stage(a, res_decode(a, tb + slot), 0, xoff, wq, lane);
+  __syncthreads();                                   // the parameter table is in LDS
+  ResTile tcur = res_decode(tabL, a.n_groups, tb + slot + grp * nslots < te ? tb + slot + grp * nslots : tb + slot);   // the tile my group staged last
+  if (grp == 0 && !(a.dbg & 1)) res_stage(tabL, a.zeros, tcur, 0, xoff, wq, lane);
 
-  // Activation as max(x, 0) + ns * min(x, 0) with ns = 0 (ReLU), slope (LeakyReLU / PReLU) or 1 (none): the same values as the
+  // Activation as max(x, ns * x) (0 <= ns <= 1) or max(x, 0) + ns * min(x, 0) with ns = 0 (ReLU), slope (LeakyReLU / PReLU) or 1 (none): the same values as the
   // branchy form, and no per-element scalar branch on `act` (hipcc does not unswitch it: 64 branches per tile row).
   // The PReLU slope is read by an explicitly GLOBAL load: a flat_load (address space not provable) stays "pending" in the
   // compiler's wait-count bookkeeping for the rest of the kernel and turns every counted lgkmcnt(N) of the multiply loop into
@@ -159,6 +208,7 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResArgs a) {
   int k = 0;                                         // my next unit to multiply
 #pragma unroll 1
   for (int p = 0;; ++p) {
+    FCVSR_RES_STAMP(0);
     if ((p & 1) == grp) {
       // ================= multiply unit k: tile list index 2 * (k / NCH) + grp, chunk k % NCH ==========================
       if (k < NU) {
@@ -172,9 +222,9 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResArgs a) {
               for (int i = 0; i < 16; ++i) acc[mf][j][i] = 0.f;
         }
         if (!(a.dbg & 2)) {
-          __builtin_amdgcn_s_setprio(2);              // the multiplying wave wins VALU/MFMA issue over its SIMD partner's epilogue
+          __builtin_amdgcn_s_setprio(2);   // the multiplying wave wins VALU/MFMA issue over its SIMD partner's epilogue
           const unsigned wch = ch * (9 * CO * 128);
-          uint4 wf[2][MF], xf[2][2];
+          uint4 wf[3][MF], xf[3][2];                   // fragments are read two 16-deep steps ahead of their MFMAs
 #define FCVSR_RES_LOAD(S, SLOT)                                                                                  \
   do {                                                                                                           \
     constexpr int tap_ = (S) / 4, kk_ = (S) % 4, ky_ = tap_ / 3, kx_ = tap_ % 3;                                 \
@@ -185,14 +235,15 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResArgs a) {
   } while (0)
 #define FCVSR_RES_STEP(S)                                                                                        \
   do {                                                                                                           \
-    if ((S) + 1 < 36) FCVSR_RES_LOAD(((S) + 1) % 36, ((S) + 1) & 1);                                             \
+    if ((S) + 2 < 36) FCVSR_RES_LOAD(((S) + 2) % 36, ((S) + 2) % 3);                                             \
     _Pragma("unroll") for (int mf = 0; mf < MF; ++mf)                                                            \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
-            acc[mf][j] = mfma<BF16>(wf[(S) & 1][mf], xf[(S) & 1][j], acc[mf][j]);                                 \
-    if ((S) + 1 < 36) __builtin_amdgcn_sched_group_barrier(0x100, MF + 2, 0);                                    \
+            acc[mf][j] = mfma<BF16>(wf[(S) % 3][mf], xf[(S) % 3][j], acc[mf][j]);                                 \
+    if ((S) + 2 < 36) __builtin_amdgcn_sched_group_barrier(0x100, MF + 2, 0);                                    \
     __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF, 0);                                                      \
   } while (0)
           FCVSR_RES_LOAD(0, 0);
+          FCVSR_RES_LOAD(1, 1);
           __builtin_amdgcn_sched_barrier(0);
           FCVSR_RES_STEP(0);  FCVSR_RES_STEP(1);  FCVSR_RES_STEP(2);  FCVSR_RES_STEP(3);  FCVSR_RES_STEP(4);  FCVSR_RES_STEP(5);
           FCVSR_RES_STEP(6);  FCVSR_RES_STEP(7);  FCVSR_RES_STEP(8);  FCVSR_RES_STEP(9);  FCVSR_RES_STEP(10); FCVSR_RES_STEP(11);
@@ -204,43 +255,88 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResArgs a) {
 #undef FCVSR_RES_LOAD
           __builtin_amdgcn_s_setprio(0);
         }
+        FCVSR_RES_STAMP(1);
+        // Bias and activation on the multiplying side, in the accumulator layout (lane = pixel r, registers 4g..4g+3 = couts
+        // mf*32 + 8g + 4h + [0,4)): the storing wave of the NEXT phase is the longer of the two roles (it shares its SIMD's issue
+        // slots with a partner that has priority), so every VALU instruction moved here shortens the phase.  With a 16-bit
+        // destination and no residual the values are also packed here (registers 2g, 2g+1 of each fragment hold quad g).
+        if (ch == NCH - 1 && !(a.dbg & 8)) {
+          const float* bias_a = reinterpret_cast<const float*>(lds + kRBiasOff) + 4 * h;
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bias_a + mf * 32 + 8 * g);
+                float v[4] = {acc[mf][j][4 * g] + b4.x, acc[mf][j][4 * g + 1] + b4.y, acc[mf][j][4 * g + 2] + b4.z,
+                              acc[mf][j][4 * g + 3] + b4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = NSU ? fmaxf(v[e], ns * v[e]) : fmaxf(v[e], 0.f) + ns * fminf(v[e], 0.f);
+                if (FAST) {
+                  const uint2 pk = cvt4<BF16>(make_float4(v[0], v[1], v[2], v[3]));
+                  acc[mf][j][2 * g] = __uint_as_float(pk.x);
+                  acc[mf][j][2 * g + 1] = __uint_as_float(pk.y);
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) acc[mf][j][4 * g + e] = v[e];
+                }
+              }
+        }
       }
       ++k;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS reads are complete before the other phase's copy overwrites
+      FCVSR_RES_STAMP(2);
     } else {
       // ================= copy unit k into my buffer; store the tile whose last chunk was unit k - 1 =======================
-      if (k < NU && !(a.dbg & 1)) {
-        const int li = 2 * (k / NCH) + grp;
-        res_stage(a, res_decode(a, tb + slot + li * nslots), (NCH == 1) ? 0 : (k & (NCH - 1)), xoff, wq, lane);
+      ResTile tn = tcur;                             // one decode per tile: the copy below and the stores two phases later share it
+      if (k < NU) {
+        const int ch = (NCH == 1) ? 0 : (k & (NCH - 1));
+        if (ch == 0 && k > 0) tn = res_decode(tabL, a.n_groups, tb + slot + (2 * (k / NCH) + grp) * nslots);
+        if (!(a.dbg & 1)) res_stage(tabL, a.zeros, tn, ch, xoff, wq, lane);
       }
+      FCVSR_RES_STAMP(3);
       int nst = 0;                                   // store wave-instructions issued below (wave-uniform)
       if (k >= 1 && k <= NU && ((k - 1) & (NCH - 1)) == NCH - 1 && !(a.dbg & 8)) {
         // Branch-free up to the stores: every load of a tile row (bias from LDS, residuals from HBM) is issued before the first
         // use, so a row costs one memory round trip instead of one per 8-channel chunk.
-        const int li = 2 * ((k - 1) / NCH) + grp;
-        const ResTile t = res_decode(a, tb + slot + li * nslots);
-        const ResGroup& G = a.g[t.gi];
-        const View dv = G.dst, r0v = G.res[0], r1v = G.res[1];
+        const ResTile t = tcur;
+        const int* T = tabL + t.gi * 32;
+        const int GH = T[kTH], GW = T[kTW];
+        gchar_t* dbase = tab_ptr(T, kTDstLo);
+        const gchar_t* r0base = tab_ptr(T, kTR0Lo);
+        const gchar_t* r1base = tab_ptr(T, kTR1Lo);
         const int px = t.tx0 + r;
-        const float* bias_s = reinterpret_cast<const float*>(lds + kRWBytes + 2 * kRXBytes) + 8 * h;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if (j) __builtin_amdgcn_sched_barrier(0);    // one row at a time: hoisting both rows' loads spills
           const int py = t.ty0 + 2 * wq + j;
-          const bool ok = (py < G.H) && (px < G.W) && !(a.dbg & 4);
+          const bool ok = (py < GH) && (px < GW) && !(a.dbg & 4);
           // lanes outside the image read the residuals of the image's first pixel (always a valid address) and store nothing
           const int pyc = ok ? py : 0, pxc = ok ? px : 0;
-          const long long dpix = (long long)t.b * dv.sb + (long long)pyc * dv.sy + (long long)pxc * dv.sx + n0 + 8 * h;
-          const long long r0pix = (long long)t.b * r0v.sb + (long long)pyc * r0v.sy + (long long)pxc * r0v.sx + n0 + 8 * h;
-          const long long r1pix = (long long)t.b * r1v.sb + (long long)pyc * r1v.sy + (long long)pxc * r1v.sx + n0 + 8 * h;
+          const unsigned dpix = (unsigned)(t.b * T[kTDstSb] + pyc * T[kTDstSy] + pxc * T[kTDstSx] + n0 + 8 * h);   // elements
+          const unsigned r0pix = (unsigned)(t.b * T[kTR0Sb] + pyc * T[kTR0Sy] + pxc * T[kTR0Sx] + n0 + 8 * h);
+          const unsigned r1pix = (unsigned)(t.b * T[kTR1Sb] + pyc * T[kTR1Sy] + pxc * T[kTR1Sx] + n0 + 8 * h);
+          if (FAST) {
+            // packed by the multiplying wave: quads 2q, 2q+1 (two dwords each) of the two half-waves -> one 16-byte store
+            if (__builtin_amdgcn_ballot_w64(ok) != 0) nst += MF * 2;
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                typedef __attribute__((ext_vector_type(2))) unsigned u2_t;
+                const u2_t s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mf][j][4 * q]), __float_as_uint(acc[mf][j][4 * q + 2]), false, false);
+                const u2_t s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mf][j][4 * q + 1]), __float_as_uint(acc[mf][j][4 * q + 3]), false, false);
+                if (ok) *reinterpret_cast<guint4_t*>(dbase + (size_t)(dpix + mf * 32 + 16 * q) * 2) = make_uint4(s0.x, s1.x, s0.y, s1.y);
+              }
+            continue;
+          }
           // accumulator quads 2q, 2q+1 of the two half-waves -> 8 consecutive couts mf*32 + 16q + 8h + [0, 8) of pixel r
           float x[MF][2][8];
 #pragma unroll
           for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-              const float4 b0 = *reinterpret_cast<const float4*>(bias_s + mf * 32 + 16 * q);
-              const float4 b1 = *reinterpret_cast<const float4*>(bias_s + mf * 32 + 16 * q + 4);
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 typedef __attribute__((ext_vector_type(2))) unsigned u2_t;
@@ -249,16 +345,11 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResArgs a) {
                 x[mf][q][e] = __uint_as_float(sw.x);
                 x[mf][q][4 + e] = __uint_as_float(sw.y);
               }
-              x[mf][q][0] += b0.x; x[mf][q][1] += b0.y; x[mf][q][2] += b0.z; x[mf][q][3] += b0.w;
-              x[mf][q][4] += b1.x; x[mf][q][5] += b1.y; x[mf][q][6] += b1.z; x[mf][q][7] += b1.w;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) x[mf][q][e] = fmaxf(x[mf][q][e], 0.f) + ns * fminf(x[mf][q][e], 0.f);
-            }
 #pragma unroll
           for (int ri = 0; ri < 2; ++ri) {
             if (ri < a.n_res) {
-              const float* rp = ri == 0 ? r0v.p : r1v.p;
-              const long long rpix = ri == 0 ? r0pix : r1pix;
+              const gchar_t* rp = ri == 0 ? r0base : r1base;
+              const unsigned rpix = ri == 0 ? r0pix : r1pix;
               const float rs = a.rs[ri];
               if (r16) {
                 uint4 v[MF][2];
@@ -266,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResArgs a) {
                 for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
                   for (int q = 0; q < 2; ++q)
-                    v[mf][q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(rp) + rpix + mf * 32 + 16 * q);
+                    v[mf][q] = *reinterpret_cast<const guint4_t*>(rp + (size_t)(rpix + mf * 32 + 16 * q) * 2);
 #pragma unroll
                 for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
@@ -283,8 +374,8 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResArgs a) {
                 for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
                   for (int q = 0; q < 2; ++q) {
-                    v[mf][q][0] = *reinterpret_cast<const float4*>(rp + rpix + mf * 32 + 16 * q);
-                    v[mf][q][1] = *reinterpret_cast<const float4*>(rp + rpix + mf * 32 + 16 * q + 4);
+                    v[mf][q][0] = *reinterpret_cast<const gfloat4_t*>(rp + (size_t)(rpix + mf * 32 + 16 * q) * 4);
+                    v[mf][q][1] = *reinterpret_cast<const gfloat4_t*>(rp + (size_t)(rpix + mf * 32 + 16 * q + 4) * 4);
                   }
 #pragma unroll
                 for (int mf = 0; mf < MF; ++mf)
@@ -308,15 +399,17 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResArgs a) {
                 const float* xx = x[mf][q];
                 if (DST16) {
                   const uint2 lo = cvt4<BF16>(make_float4(xx[0], xx[1], xx[2], xx[3])), hi = cvt4<BF16>(make_float4(xx[4], xx[5], xx[6], xx[7]));
-                  *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(dv.p) + dpix + mf * 32 + 16 * q) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                  *reinterpret_cast<guint4_t*>(dbase + (size_t)(dpix + mf * 32 + 16 * q) * 2) = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 } else {
-                  *reinterpret_cast<float4*>(dv.p + dpix + mf * 32 + 16 * q) = make_float4(xx[0], xx[1], xx[2], xx[3]);
-                  *reinterpret_cast<float4*>(dv.p + dpix + mf * 32 + 16 * q + 4) = make_float4(xx[4], xx[5], xx[6], xx[7]);
+                  *reinterpret_cast<gfloat4_t*>(dbase + (size_t)(dpix + mf * 32 + 16 * q) * 4) = make_float4(xx[0], xx[1], xx[2], xx[3]);
+                  *reinterpret_cast<gfloat4_t*>(dbase + (size_t)(dpix + mf * 32 + 16 * q + 4) * 4) = make_float4(xx[4], xx[5], xx[6], xx[7]);
                 }
               }
           }
         }
       }
+      tcur = tn;
+      FCVSR_RES_STAMP(4);
       // My copies must have landed before the barrier; my stores need not have.  vmcnt counts loads, LDS-DMA and stores
       // together in issue order, and the stores are the youngest operations: leave exactly them outstanding (waiting for them
       // too exposes a full HBM write round trip per phase - measured 78 vs 54 us on a 64->64 layer).
@@ -324,7 +417,9 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResArgs a) {
       if (nst == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (nst == SR) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SR) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SR) : "memory");
+      FCVSR_RES_STAMP(5);
     }
+    FCVSR_RES_STAMP(6);
     __builtin_amdgcn_s_barrier();
     if (p >= plast) break;
   }
@@ -332,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResArgs a) {
 
 bool conv3_res_supports(int cin, int cout) { return (cin == 64 && cout % 64 == 0) || (cin == 128 && cout % 32 == 0); }
 
-template <bool BF16, bool DST16, int NCH>
+template <bool BF16, int MODE, int NCH, bool NSU>
 static hipError_t launch_res(const ResArgs& a, hipStream_t st) {
   static int n_cu = 0;
   if (!n_cu) {
@@ -342,7 +437,7 @@ static hipError_t launch_res(const ResArgs& a, hipStream_t st) {
     hipDeviceProp_t prop;
     e = hipGetDeviceProperties(&prop, dev);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)conv3_res_kernel<BF16, DST16, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRLds);
+    e = hipFuncSetAttribute((const void*)conv3_res_kernel<BF16, MODE, NCH, NSU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRLds);
     if (e != hipSuccess) return e;
     n_cu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
   }
@@ -352,18 +447,48 @@ static hipError_t launch_res(const ResArgs& a, hipStream_t st) {
   if (grid < 8 * NB) grid = 8 * NB;
   const int need = (a.total_tiles + 7) / 8 * 8 * NB;
   if (grid > need) grid = need;
-  hipLaunchKernelGGL((conv3_res_kernel<BF16, DST16, NCH>), dim3(grid), dim3(512), kRLds, st, a);
+  ResK k;
+  k.n_groups = a.n_groups; k.total_tiles = a.total_tiles; k.cout = a.cout; k.cout_pad = a.cout_pad; k.cin_pad = a.cin_pad;
+  k.act = a.act; k.n_res = a.n_res; k.res16 = a.res16; k.dbg = a.dbg; k.slope = a.slope; k.rs[0] = a.rs[0]; k.rs[1] = a.rs[1];
+  k.slope_ptr = a.slope_ptr; k.w = a.w; k.bias = a.bias; k.zeros = a.zeros; k.stamps = a.stamps;
+  for (int g = 0; g < 3; ++g) {
+    const ResGroup& G = a.g[g < a.n_groups ? g : 0];
+    int* T = k.tab[g];
+    for (int i = 0; i < 32; ++i) T[i] = 0;
+    auto put = [&](int lo, const void* p) { T[lo] = (int)(unsigned)((uintptr_t)p & 0xffffffffu); T[lo + 1] = (int)(unsigned)((uintptr_t)p >> 32); };
+    put(kTSrcLo, G.src.p);
+    T[kTSrcSb2] = (int)(G.src.sb * 2); T[kTSrcSy2] = (int)(G.src.sy * 2); T[kTSrcSx2] = (int)(G.src.sx * 2);
+    T[kTH] = G.H; T[kTW] = G.W; T[kTTilesX] = G.tiles_x; T[kTPerImg] = G.tiles_x * G.tiles_y;
+    T[kTTileBegin] = g < a.n_groups ? G.tile_begin : 0x7fffffff;
+    put(kTDstLo, G.dst.p); T[kTDstSb] = (int)G.dst.sb; T[kTDstSy] = (int)G.dst.sy; T[kTDstSx] = (int)G.dst.sx;
+    const View& r0 = a.n_res > 0 ? G.res[0] : G.dst;      // unused residual slots alias the destination (valid addresses)
+    const View& r1 = a.n_res > 1 ? G.res[1] : G.dst;
+    put(kTR0Lo, r0.p); T[kTR0Sb] = (int)r0.sb; T[kTR0Sy] = (int)r0.sy; T[kTR0Sx] = (int)r0.sx;
+    put(kTR1Lo, r1.p); T[kTR1Sb] = (int)r1.sb; T[kTR1Sy] = (int)r1.sy; T[kTR1Sx] = (int)r1.sx;
+  }
+  hipLaunchKernelGGL((conv3_res_kernel<BF16, MODE, NCH, NSU>), dim3(grid), dim3(512), kRLds, st, k);
   return hipGetLastError();
+}
+
+template <bool BF16, int NCH>
+static hipError_t launch_res_mode(const ResArgs& a, bool dst16, hipStream_t st) {
+  // act(x) = max(x, ns * x) needs 0 <= ns <= 1: known on the host for every activation but PReLU (slope in device memory)
+  const bool nsu = a.act == FCVSR_ACT_NONE || a.act == FCVSR_ACT_RELU || (a.act == FCVSR_ACT_LEAKY && a.slope >= 0.f && a.slope <= 1.f);
+  const int mode = !dst16 ? 0 : (a.n_res == 0 ? 2 : 1);
+  if (nsu) {
+    if (mode == 0) return launch_res<BF16, 0, NCH, true>(a, st);
+    if (mode == 1) return launch_res<BF16, 1, NCH, true>(a, st);
+    return launch_res<BF16, 2, NCH, true>(a, st);
+  }
+  if (mode == 0) return launch_res<BF16, 0, NCH, false>(a, st);
+  if (mode == 1) return launch_res<BF16, 1, NCH, false>(a, st);
+  return launch_res<BF16, 2, NCH, false>(a, st);
 }
 
 hipError_t launch_conv3_res(const ResArgs& a, bool bf16, bool dst16, hipStream_t st) {
   if (!conv3_res_supports(a.cin, a.cout)) return hipErrorInvalidValue;
-  if (a.cin == 64) {
-    if (bf16) return dst16 ? launch_res<true, true, 1>(a, st) : launch_res<true, false, 1>(a, st);
-    return dst16 ? launch_res<false, true, 1>(a, st) : launch_res<false, false, 1>(a, st);
-  }
-  if (bf16) return dst16 ? launch_res<true, true, 2>(a, st) : launch_res<true, false, 2>(a, st);
-  return dst16 ? launch_res<false, true, 2>(a, st) : launch_res<false, false, 2>(a, st);
+  if (a.cin == 64) return bf16 ? launch_res_mode<true, 1>(a, dst16, st) : launch_res_mode<false, 1>(a, dst16, st);
+  return bf16 ? launch_res_mode<true, 2>(a, dst16, st) : launch_res_mode<false, 2>(a, dst16, st);
 }
 
 }  // namespace fcvsr

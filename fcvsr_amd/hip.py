@@ -67,6 +67,7 @@ _PV = C.POINTER(View)
 SIGNATURES = {
     "fcvsr_last_error": [],
     "fcvsr_last_conv_kernel": [],
+    "fcvsr_debug_res_stamps": [C.c_void_p, C.c_size_t],
     "fcvsr_abi_version": [],
     "fcvsr_device_count": [],
     "fcvsr_conv2d": [C.POINTER(ConvDesc), _VP],

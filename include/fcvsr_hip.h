@@ -91,6 +91,9 @@ int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int mma_dtype,
 /* Name (template instance) of the kernel the calling thread's last fcvsr_conv2d_mfma call launched, e.g.
  * "conv3_res_kernel<true, true, 1>": measurement aid for bench.py's per-kernel roofline, not part of the data path. */
 const char* fcvsr_last_conv_kernel(void);
+/* Diagnostic (FCVSR_RES_STAMPS=1 in the environment): copies the in-kernel cycle stamps the last resident-weight convolution
+ * launch recorded for one workgroup, [wave 8][phase 64][slot 8] uint64, to host memory.  Not part of the data path. */
+int fcvsr_debug_res_stamps(void* host_out, size_t bytes);
 
 /* ---- frequency transforms: torch.fft.rfft2 / irfft2 (norm='backward') of NHWC channel groups -------------
  * Spectrum layout: buffer [B][H][Wf][pix_stride] with Wf=W/2+1; channel c of the group has its imaginary part at

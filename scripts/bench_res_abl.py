@@ -8,7 +8,7 @@ def main():
     os.environ["FCVSR_MFMA_RES"] = "1"
     for cin, cout, B, levels in ((64, 64, 16, L3[:1]), (64, 128, 16, L3), (128, 64, 16, L3)):
         wp, bias, groups, flops = make(cin, cout, B, levels, True, 0)
-        for dbg in (0, 16, 2, 18, 0, 16):
+        for dbg in (0, 32, 64, 96, 0, 32, 64, 96, 2, 13):
             os.environ["FCVSR_RES_DBG"] = str(dbg)
             us = timeit(lambda: run(groups, wp, bias, cout, 0))
             print(f"{cin}->{cout} B={B} levels={len(levels)} dbg={dbg}: {us:8.1f} us ({flops/us/1e6:7.1f} TF/s nominal)", flush=True)

@@ -4,7 +4,7 @@ import torch
 from fcvsr_amd import hip
 dt, mdt = torch.bfloat16, hip.BF16
 L3 = [(180, 320), (90, 160), (45, 80)]
-B, cin, cout = 8, 64, 64
+B, cin, cout = int(os.environ.get("B", "16")), int(os.environ.get("CIN", "64")), int(os.environ.get("COUT", "64"))
 w = torch.randn(cout, cin, 3, 3, device="cuda") / 24
 wp = hip.pack_conv_weight_mfma(w, dt)
 io = torch.bfloat16 if os.environ.get("IO16", "1") == "1" else torch.float32       # default: the bench's dominant variant

@@ -80,8 +80,14 @@ __device__ __forceinline__ ResTile res_decode(const int* tabL, int n_groups, int
 // Pointers rebuilt from table words are declared GLOBAL (address space 1): a generic pointer makes hipcc emit flat_load /
 // flat_store, which count on lgkmcnt as well and turn every counted LDS wait of the multiply loop into lgkmcnt(0).
 typedef __attribute__((address_space(1))) char gchar_t;
-typedef __attribute__((address_space(1))) uint4 guint4_t;
-typedef __attribute__((address_space(1))) float4 gfloat4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;      // plain vectors: HIP's uint4 / float4 classes have no
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;         // address-space-qualified assignment operators
+typedef __attribute__((address_space(1))) u32x4_t guint4_t;
+typedef __attribute__((address_space(1))) f32x4_t gfloat4_t;
+__device__ __forceinline__ void gstore(gchar_t* p, uint4 v) { *reinterpret_cast<guint4_t*>(p) = u32x4_t{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void gstore(gchar_t* p, float4 v) { *reinterpret_cast<gfloat4_t*>(p) = f32x4_t{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ uint4 gload_u4(const gchar_t* p) { const u32x4_t v = *reinterpret_cast<const guint4_t*>(p); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float4 gload_f4(const gchar_t* p) { const f32x4_t v = *reinterpret_cast<const gfloat4_t*>(p); return make_float4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ gchar_t* tab_ptr(const int* T, int lo) {
   return reinterpret_cast<gchar_t*>(((unsigned long long)(unsigned)T[lo + 1] << 32) | (unsigned)T[lo]);
 }
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResK a) {
                 typedef __attribute__((ext_vector_type(2))) unsigned u2_t;
                 const u2_t s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mf][j][4 * q]), __float_as_uint(acc[mf][j][4 * q + 2]), false, false);
                 const u2_t s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mf][j][4 * q + 1]), __float_as_uint(acc[mf][j][4 * q + 3]), false, false);
-                if (ok) *reinterpret_cast<guint4_t*>(dbase + (size_t)(dpix + mf * 32 + 16 * q) * 2) = make_uint4(s0.x, s1.x, s0.y, s1.y);
+                if (ok) gstore(dbase + (size_t)(dpix + mf * 32 + 16 * q) * 2, make_uint4(s0.x, s1.x, s0.y, s1.y));
               }
             continue;
           }
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResK a) {
                 for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
                   for (int q = 0; q < 2; ++q)
-                    v[mf][q] = *reinterpret_cast<const guint4_t*>(rp + (size_t)(rpix + mf * 32 + 16 * q) * 2);
+                    v[mf][q] = gload_u4(rp + (size_t)(rpix + mf * 32 + 16 * q) * 2);
 #pragma unroll
                 for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
@@ -374,8 +380,8 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResK a) {
                 for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
                   for (int q = 0; q < 2; ++q) {
-                    v[mf][q][0] = *reinterpret_cast<const gfloat4_t*>(rp + (size_t)(rpix + mf * 32 + 16 * q) * 4);
-                    v[mf][q][1] = *reinterpret_cast<const gfloat4_t*>(rp + (size_t)(rpix + mf * 32 + 16 * q + 4) * 4);
+                    v[mf][q][0] = gload_f4(rp + (size_t)(rpix + mf * 32 + 16 * q) * 4);
+                    v[mf][q][1] = gload_f4(rp + (size_t)(rpix + mf * 32 + 16 * q + 4) * 4);
                   }
 #pragma unroll
                 for (int mf = 0; mf < MF; ++mf)
@@ -399,10 +405,10 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResK a) {
                 const float* xx = x[mf][q];
                 if (DST16) {
                   const uint2 lo = cvt4<BF16>(make_float4(xx[0], xx[1], xx[2], xx[3])), hi = cvt4<BF16>(make_float4(xx[4], xx[5], xx[6], xx[7]));
-                  *reinterpret_cast<guint4_t*>(dbase + (size_t)(dpix + mf * 32 + 16 * q) * 2) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                  gstore(dbase + (size_t)(dpix + mf * 32 + 16 * q) * 2, make_uint4(lo.x, lo.y, hi.x, hi.y));
                 } else {
-                  *reinterpret_cast<gfloat4_t*>(dbase + (size_t)(dpix + mf * 32 + 16 * q) * 4) = make_float4(xx[0], xx[1], xx[2], xx[3]);
-                  *reinterpret_cast<gfloat4_t*>(dbase + (size_t)(dpix + mf * 32 + 16 * q + 4) * 4) = make_float4(xx[4], xx[5], xx[6], xx[7]);
+                  gstore(dbase + (size_t)(dpix + mf * 32 + 16 * q) * 4, make_float4(xx[0], xx[1], xx[2], xx[3]));
+                  gstore(dbase + (size_t)(dpix + mf * 32 + 16 * q + 4) * 4, make_float4(xx[4], xx[5], xx[6], xx[7]));
                 }
               }
           }

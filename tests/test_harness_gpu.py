@@ -34,3 +34,28 @@ def test_sequence_harness_matches_per_window_oracle():
     diff = np.abs(sr.astype(np.int32) - ref.astype(np.int32))
     assert diff.max() <= 1 and (diff > 0).mean() < 2e-3        # truncation can flip a value sitting on an integer boundary
     assert sequence_psnr(sr, ref, crop_border=4) > 70.0
+
+
+def test_streamed_scheduler_on_the_hip_model_equals_the_sequence_harness():
+    """BASELINE config 5 (scaled down): several sequences streamed in fixed-size batches through pinned double buffers, split
+    over two ranks, reproduce the per-sequence harness bit for bit (clips are independent; every call has the same shape)."""
+    from fcvsr_amd.arch.CVSR_freq import GShiftNet_S
+    from fcvsr_amd.arch.schema import state_dict_shapes
+    from fcvsr_amd.harness.infer import StreamedSuperResolver, super_resolve_sequence, sequence_ssim
+    from fcvsr_amd.weights import synthetic_state_dict
+    sd = synthetic_state_dict(state_dict_shapes("GShiftNet_S"))
+    model = GShiftNet_S()
+    model.load_state_dict(sd)
+    model = model.cuda()
+    model.precision = "bf16"
+    rs = np.random.RandomState(7)
+    seqs = [torch.from_numpy((rs.randint(0, 256, (n, 1, 18, 20)) / 255.0).astype(np.float32)) for n in (7, 5)]
+    ref = [super_resolve_sequence(model, s, batch=4) for s in seqs]
+    for world in (1, 2):
+        got = {i: np.zeros_like(r) for i, r in enumerate(ref)}
+        for rank in range(world):
+            for s, (first, arr) in StreamedSuperResolver(model, batch=4).run(seqs, rank=rank, world=world).items():
+                got[s][first:first + len(arr)] = arr
+        for i in range(len(seqs)):
+            assert np.array_equal(got[i], ref[i])
+    assert sequence_ssim(ref[0], ref[0]) == pytest.approx(1.0)

@@ -220,7 +220,17 @@ class _GShiftBase(nn.Module):
             self._engine.invalidate()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """x: float (B, 7, C, H, W) in [0,1] on a HIP device -> (B, C, 4H, 4W)."""
+        """x: float (B, 7, C, H, W) in [0,1] on a HIP device -> (B, C, 4H, 4W).
+
+        Under autograd (gradients enabled and a parameter or the input requires one - the reference's training loop,
+        train_LD_freqCVSR_S_22.py:244-251) the differentiable graph of ``fcvsr_amd.train`` runs: HIP convolution kernels in
+        the forward, input-gradient and weight-gradient directions, torch operators for the rest.  Otherwise (inference,
+        ``torch.no_grad()``) every operator is a hand-written kernel driven by ``fcvsr_amd.engine``."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from ..train.graph import forward_train
+            if x.dim() != 5 or x.shape[1] != self._in_frames or x.shape[2] != self._img_ch:
+                raise ValueError(f"expected (B,{self._in_frames},{self._img_ch},H,W) input, got {tuple(x.shape)}")
+            return forward_train(self.state_dict(keep_vars=True), x, precision=getattr(self, "train_precision", self.precision))
         from ..engine import Engine
         if self._engine is None or self._engine._model() is not self:      # (a deepcopy carries the source's engine)
             object.__setattr__(self, "_engine", Engine(self))

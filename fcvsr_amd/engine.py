@@ -637,11 +637,6 @@ class Engine:
     # ---------------------------------------------------------------------------------------------- top level
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         m = self._model()
-        if torch.is_grad_enabled() and not self._warned and any(p.requires_grad for p in m.parameters()):
-            import warnings
-            warnings.warn("fcvsr_amd: backward through the HIP path is not implemented yet; the output is detached "
-                          "(wrap inference in torch.no_grad() to silence this)")
-            self._warned = True
         with torch.no_grad():
             return self._forward_checked(x, m)
 

@@ -68,6 +68,9 @@ SIGNATURES = {
     "fcvsr_last_error": [],
     "fcvsr_last_conv_kernel": [],
     "fcvsr_debug_res_stamps": [C.c_void_p, C.c_size_t],
+    "fcvsr_conv2d_wgrad_scratch_elems": [C.c_int] * 7,
+    "fcvsr_conv2d_wgrad": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                           C.c_longlong, C.c_void_p],
     "fcvsr_abi_version": [],
     "fcvsr_device_count": [],
     "fcvsr_conv2d": [C.POINTER(ConvDesc), _VP],
@@ -102,7 +105,7 @@ SIGNATURES = {
     "fcvsr_bilinear_up4": [_PV, _I, _I, _I, _PV, _VP],
     "fcvsr_tail_fused": [_PV, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _PV, _VP],
 }
-_RESTYPES = {"fcvsr_last_error": C.c_char_p, "fcvsr_last_conv_kernel": C.c_char_p}
+_RESTYPES = {"fcvsr_last_error": C.c_char_p, "fcvsr_last_conv_kernel": C.c_char_p, "fcvsr_conv2d_wgrad_scratch_elems": C.c_longlong}
 
 
 def lib() -> C.CDLL:
@@ -135,6 +138,8 @@ def view(t: torch.Tensor) -> View:
     """View of a 4-D tensor whose logical dims are (b, y, x, c) with arbitrary strides (zero-copy)."""
     assert t.dim() == 4, t.shape
     sb, sy, sx, sc = t.stride()
+    if t.shape[3] == 1:
+        sc = 1                                   # the stride of a size-1 dimension is arbitrary in torch (channels_last with C = 1)
     return View(t.data_ptr(), sb, sy, sx, sc, t.shape[3], _DT[t.dtype])
 
 

@@ -1,0 +1,242 @@
+"""Differentiable forward of GShiftNet_S / GShiftNet (and the RGB twins) for training: the function the reference trains
+through (`sr = model(frames)`; `loss.backward()`, CVSR_train/train_LD_freqCVSR_S_22.py:244-251; forward definition
+CVSR_train/arch/CVSR_freq.py:2611-2646 / :2688-2756, specification SURVEY.md Appendix A).
+
+Every nn.Conv2d of the path (98 % of the FLOPs) runs on the HIP kernels in all three directions through
+`fcvsr_amd.train.ops.conv2d`; the remaining operators (FFTs, CorrBlock lookup, bilinear warp, separable adaptive 3-tap
+convolution, ContextBlock softmax pool, bilinear resampling) are device-side torch operators whose backward torch derives.
+This is the training counterpart of `fcvsr_amd.engine` (inference: every operator a hand-written kernel, no autograd); it is
+selected automatically by the drop-in modules when gradients are required.  Device tensors only - no CPU fallback.
+
+`p` maps the reference's state_dict keys to the live nn.Parameters of the drop-in module.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+
+from ..engine import band_masks_half
+from .ops import conv2d
+
+Tensor = torch.Tensor
+
+
+class _Ctx:
+    def __init__(self, p: Dict[str, Tensor], precision: str):
+        self.p, self.precision = p, precision
+
+    def conv(self, key: str, x: Tensor, stride: int = 1) -> Tensor:
+        return conv2d(x, self.p[key + ".weight"], self.p.get(key + ".bias"), stride, self.precision)
+
+    def chain(self, key: str, t: Tensor, n: int) -> Tensor:
+        """n bias-free 1x1 convolutions with ReLU in between (convfuse / convcrt / convcorr, CVSR_freq.py:1371-1396)."""
+        for li in range(n):
+            t = conv2d(t, self.p[f"{key}.{2 * li}.weight"], None, 1, self.precision)
+            if li < n - 1:
+                t = F.relu(t)
+        return t
+
+    def ca(self, key: str, z: Tensor) -> Tensor:
+        """CALayer (:1812-1828): z * sigmoid(W2 relu(W1 mean_HW(z))); the two 1x1 convolutions act on a (B,C) vector."""
+        y = z.mean(dim=(2, 3))
+        y = F.relu(y @ self.p[key + ".conv_du.0.weight"].flatten(1).t())
+        y = torch.sigmoid(y @ self.p[key + ".conv_du.2.weight"].flatten(1).t())
+        return z * y[:, :, None, None]
+
+
+def _lrelu(x: Tensor, s: float) -> Tensor:
+    return torch.where(x >= 0, x, x * s)
+
+
+def _prelu(x: Tensor, a: Tensor) -> Tensor:
+    return torch.where(x >= 0, x, x * a.reshape(1, -1, 1, 1))
+
+
+def _ps2(x: Tensor) -> Tensor:
+    return F.pixel_shuffle(x, 2)
+
+
+def _spec(x: Tensor) -> Tensor:
+    X = torch.fft.rfft2(x.contiguous(), norm="backward")
+    return torch.cat([X.imag, X.real], dim=1)                       # imag first (:1456-1465)
+
+
+def _corr_lookup(x1f: Tensor, x2f: Tensor, radius: int = 4) -> Tensor:
+    """CorrBlock on the un-updated integer grid = bounds-checked gather from the raw-viewed product (:1279-1337);
+    non-zero only for x <= 5, y <= 67."""
+    B, C, H, Wf = x1f.shape
+    n = 2 * radius + 1
+    dev = x1f.device
+    img = ((x1f * x2f).contiguous().reshape(B, C * H * Wf) / math.sqrt(float(C))).reshape(B, H * Wf, C // 2, 2)
+    ys = torch.arange(H, device=dev).view(H, 1).expand(H, Wf)
+    xs = torch.arange(Wf, device=dev).view(1, Wf).expand(H, Wf)
+    pix = ys * Wf + xs
+    planes = []
+    zero = torch.zeros(B, H, Wf, dtype=x1f.dtype, device=dev)
+    for i in range(n):
+        col = xs + (i - radius)
+        cok = (col >= 0) & (col <= 1)
+        for j in range(n):
+            row = ys + (j - radius)
+            ok = cok & (row >= 0) & (row <= C // 2 - 1)
+            if not bool(ok.any()):
+                planes.append(zero)
+                continue
+            v = img[:, pix, row.clamp(0, C // 2 - 1), col.clamp(0, 1)]
+            planes.append(v * ok.to(v.dtype))
+    return torch.stack(planes, 1)
+
+
+def _warp(x: Tensor, off: Tensor) -> Tensor:
+    """flow_warp (:1188-1227): bilinear sample of x at (col + off[:,0], row + off[:,1]), zeros outside; differentiable in both."""
+    B, C, H, W = x.shape
+    dev = x.device
+    sx = torch.arange(W, dtype=x.dtype, device=dev).view(1, 1, W) + off[:, 0]
+    sy = torch.arange(H, dtype=x.dtype, device=dev).view(1, H, 1) + off[:, 1]
+    x0, y0 = torch.floor(sx), torch.floor(sy)
+    wx1, wy1 = sx - x0, sy - y0
+    flat = x.contiguous().reshape(B, C, H * W)
+    out = None
+    for dy, wy in ((0, 1 - wy1), (1, wy1)):
+        for dx, wx in ((0, 1 - wx1), (1, wx1)):
+            xi, yi = (x0 + dx).long(), (y0 + dy).long()
+            ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+            idx = (yi.clamp(0, H - 1) * W + xi.clamp(0, W - 1)).view(B, 1, H * W).expand(B, C, H * W)
+            v = torch.gather(flat, 2, idx).view(B, C, H, W) * (wy * wx * ok.to(x.dtype)).unsqueeze(1)
+            out = v if out is None else out + v
+    return out
+
+
+def _sac(s: Tensor, k1: Tensor) -> Tensor:
+    """SAC (:1253-1276): vertical then horizontal adaptive 3-tap, replicate padding, kernel1 in BOTH passes (:1272-1273)."""
+    B, C, H, W = s.shape
+    k = k1.reshape(B, C, 3, H, W)
+    sp = F.pad(s, (0, 0, 1, 1), mode="replicate")
+    v = sp[:, :, 0:H] * k[:, :, 0] + sp[:, :, 1:H + 1] * k[:, :, 1] + sp[:, :, 2:H + 2] * k[:, :, 2]
+    vp = F.pad(v, (1, 1, 0, 0), mode="replicate")
+    return vp[..., 0:W] * k[:, :, 0] + vp[..., 1:W + 1] * k[:, :, 1] + vp[..., 2:W + 2] * k[:, :, 2]
+
+
+def _mgaa(c: _Ctx, key: str, x: Tensor, A: int) -> Tensor:
+    B, C3, H, W = x.shape
+    d = C3 // 3
+    x1, x2, x3 = x[:, :d], x[:, d:2 * d], x[:, 2 * d:]
+    x1f, x2f, x3f = _spec(x1), _spec(x2), _spec(x3)
+    off_f = (x1f - x2f) + c.chain(key + ".convfuse", torch.cat([x1f, x2f], 1), 3)
+    off_b = (x3f - x2f) + c.chain(key + ".convfuse", torch.cat([x3f, x2f], 1), 3)
+    sim = c.chain(key + ".convcrt", x2f, 2)
+    corr = _corr_lookup(x1f, x2f)                                   # forward pair only, reused for both directions (:1487-1488)
+    flow0 = torch.zeros(B, 2, H, x1f.shape[-1], dtype=x.dtype, device=x.device)
+    off_f = c.chain(key + ".convcorr", torch.cat([off_f, corr, flow0], 1), 3)
+    off_b = c.chain(key + ".convcorr", torch.cat([off_b, corr, flow0], 1), 3)
+    offs: List[List[Tensor]] = [[], []]
+    for i in range(A):
+        blk = f"{key}.MConvB.{i}"
+        for src, dst in ((off_f, offs[0]), (off_b, offs[1])):
+            t = _prelu(c.conv(blk + ".conv1", src), c.p[blk + ".relu.weight"])
+            u = c.conv(blk + ".conv2", t)
+            o = (c.ca(blk + ".CA", u) + u) * sim
+            dst.append(torch.fft.irfft2(torch.complex(o[:, :2].contiguous(), o[:, 2:].contiguous()), s=(H, W), norm="backward"))
+    K = c.conv(key + ".F.1", c.conv(key + ".F.0", c.conv(key + ".conv_KP", x2)))
+    al = []
+    for feat_in, ofs in ((x1, offs[0]), (x3, offs[1])):
+        feat = feat_in
+        for i in range(A):
+            k1 = K[:, i * 6 * d: i * 6 * d + 3 * d]                # F1 half of iteration i (the F2 half is never read)
+            feat = _lrelu(_sac(_warp(feat, ofs[i]), k1) + feat_in, 0.1)
+        al.append(feat)
+    return c.conv(key + ".conv3", torch.cat(al, 1)) + x2
+
+
+def _mffr(c: _Ctx, key: str, x: Tensor, Q: int) -> Tensor:
+    B, C, H, W = x.shape
+    M = band_masks_half(Q, H, W).to(x.device)
+    X = torch.fft.rfft2(x.contiguous())
+    freq = [torch.fft.irfft2(X * M[n], s=(H, W)) for n in range(Q)][::-1]
+    s_f = torch.zeros_like(x)
+    s_o = torch.zeros_like(x)
+    for i in range(Q):
+        blk = f"{key}.DivEnh_block.{i}"
+        a, b = c.p[blk + ".a"].reshape(1, -1, 1, 1), c.p[blk + ".b"].reshape(1, -1, 1, 1)
+        f = freq[i]
+        if i == 0:
+            o = c.ca(blk + ".ca", 0.2 * a * (f - f.mean(dim=(2, 3), keepdim=True)) * f + b * f)
+        else:
+            t = f - s_f + 0.2 * s_o
+            o = c.ca(blk + ".ca", 0.2 * a * t * f + b * f) + c.ca(blk + ".ca", 0.2 * a * s_o * f + b * f)
+        s_f = s_f + f
+        s_o = s_o + o
+    return c.ca(key + ".ca", s_o) + x
+
+
+def _context_block(c: _Ctx, key: str, r: Tensor) -> Tensor:
+    B, C, H, W = r.shape
+    logits = conv2d(r, c.p[key + ".conv_mask.weight"], None, 1, "f32").reshape(B, 1, H * W)
+    m = torch.softmax(logits, dim=2)
+    ctx = (r.reshape(B, C, H * W) * m).sum(dim=2)
+    t = _lrelu(ctx @ c.p[key + ".channel_add_conv.0.weight"].flatten(1).t(), 0.2)
+    return r + (t @ c.p[key + ".channel_add_conv.2.weight"].flatten(1).t())[:, :, None, None]
+
+
+def _block_rcb(c: _Ctx, key: str, xs: List[Tensor]) -> List[Tensor]:
+    def body(z):
+        z = c.conv(key + ".body.2", _lrelu(c.conv(key + ".body.0", z), 0.1))
+        r = c.conv(key + ".RCB.body.2", _lrelu(c.conv(key + ".RCB.body.0", z), 0.2))
+        return _lrelu(_context_block(c, key + ".RCB.gcnet", r), 0.2) + z
+
+    def dn(z):
+        return F.interpolate(c.conv(key + ".down.0", z), scale_factor=0.5, mode="bilinear", align_corners=False)
+
+    def up(z):
+        return F.interpolate(c.conv(key + ".up.0", z), scale_factor=2.0, mode="bilinear", align_corners=False)
+
+    R = [body(z) for z in xs]
+    return [xs[0] + R[0] + R[0] + up(R[1]), xs[1] + R[1] + dn(R[0]) + up(R[2]), xs[2] + R[2] + dn(R[1]) + R[2]]
+
+
+def _scnet(c: _Ctx, key: str, xs: List[Tensor], G: int) -> List[Tensor]:
+    cur = xs
+    for g in range(G):
+        t = cur
+        for k in range(3):
+            t = _block_rcb(c, f"{key}.body.{g}.body.{k}", t)
+        cur = [a + c.conv(f"{key}.body.{g}.conv", r) for a, r in zip(cur, t)]
+    return [x + r for x, r in zip(xs, cur)]
+
+
+def forward_train(p: Dict[str, Tensor], x: Tensor, *, precision: str = "f32") -> Tensor:
+    """x: (B,7,C,H,W) device tensor in [0,1] -> (B,C,4H,4W), differentiable w.r.t. every live parameter in `p`."""
+    if not x.is_cuda:
+        raise RuntimeError("fcvsr_amd.train needs device tensors (the HIP path has no CPU fallback)")
+    n = p["conv_last0.weight"].shape[1]
+    A = p["MGAA.F.1.weight"].shape[0] // (6 * n)
+    Q = sum(1 for k in p if k.startswith("MFFRblock.DivEnh_block.") and k.endswith(".a"))
+    G = sum(1 for k in p if k.startswith("recorb1.body.") and k.endswith(".conv.weight") and k.count(".") == 4)
+    B, T, C, H, W = x.shape
+    if H % 4 or W % 4:
+        raise ValueError("H and W must be multiples of 4 (3-level pyramid, reference BlockRCB :766-777)")
+    c = _Ctx(p, precision)
+    feat = conv2d(x.reshape(B, T * C, H, W).float(), p["feat_extract.0.weight"], p["feat_extract.0.bias"], 1, "f32")
+    f1, f2, f3 = feat[:, :3 * n], feat[:, 3 * n:4 * n], feat[:, 4 * n:]
+    a1 = _mgaa(c, "MGAA", f1, A)
+    a3 = _mgaa(c, "MGAA", f3, A)
+    a2 = _mgaa(c, "MGAA", torch.cat([a1, f2, a3], 1), A)
+    d0 = _mffr(c, "MFFRblock", a2, Q)
+    d1 = c.conv("rconcat1", d0, stride=2)
+    d2 = c.conv("rconcat2", d1, stride=2)
+    o0, o1, o2 = _scnet(c, "recorb1", [d0, d1, d2], G)
+    a = p["lrelu.weight"]
+    l3 = _prelu(c.conv("upconv1_L3", o2), a)
+    l3_1 = _ps2(l3)
+    l3_2 = _ps2(l3_1)
+    l2 = _prelu(c.conv("upconv1_L2", o1), a)
+    l2 = _ps2(l2 + c.conv("upconv1_L2_2", torch.cat([l2, l3_1], 1)))
+    fz = c.conv("recorb0", c.conv("upconv_fuse", torch.cat([o0, l2, l3_2], 1)))
+    u = _prelu(_ps2(c.conv("upconv1", fz)), a)
+    u = _prelu(_ps2(c.conv("upconv2", u)), a)
+    out = conv2d(u, p["conv_last0.weight"], p["conv_last0.bias"], 1, "f32")
+    base = F.interpolate(x[:, T // 2].float(), scale_factor=4, mode="bilinear", align_corners=False)
+    return out + base

@@ -91,6 +91,15 @@ int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int mma_dtype,
 /* Name (template instance) of the kernel the calling thread's last fcvsr_conv2d_mfma call launched, e.g.
  * "conv3_res_kernel<true, true, 1>": measurement aid for bench.py's per-kernel roofline, not part of the data path. */
 const char* fcvsr_last_conv_kernel(void);
+/* Backward of the convolutions (reference: `loss.backward()` through nn.Conv2d, CVSR_train/train_LD_freqCVSR_S_22.py:250).
+ * The input gradient of a stride-1 "same" convolution is itself such a convolution of the output gradient with the transposed,
+ * tap-flipped weight, so it goes through fcvsr_conv2d / fcvsr_conv2d_mfma; the weight gradient is this entry point:
+ *   dw[co][ci][ky][kx] = sum_{b,oy,ox} gy[b,oy,ox,co] * x[b, oy*stride - pad + ky, ox*stride - pad + kx, ci]
+ * x: (B,H,W,cin), gy: (B,Ho,Wo,cout), both channel-contiguous f32 views; dw: f32 (cout,cin,kh,kw) = nn.Conv2d.weight layout;
+ * scratch: >= fcvsr_conv2d_wgrad_scratch_elems(...) floats.  Exact f32, fixed summation order (bit-reproducible). */
+long long fcvsr_conv2d_wgrad_scratch_elems(int B, int Ho, int Wo, int cin, int cout, int kh, int kw);
+int fcvsr_conv2d_wgrad(const fcvsr_view* x, const fcvsr_view* gy, int B, int H, int W, int kh, int kw, int stride, int pad,
+                       float* dw, float* scratch, long long scratch_elems, void* stream);
 /* Diagnostic (FCVSR_RES_STAMPS=1 in the environment): copies the in-kernel cycle stamps the last resident-weight convolution
  * launch recorded for one workgroup, [wave 8][phase 64][slot 8] uint64, to host memory.  Not part of the data path. */
 int fcvsr_debug_res_stamps(void* host_out, size_t bytes);

@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sub-records (batch-1 latency, full model, f32 mode)")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step sub-record (BASELINE config 3)")
+    ap.add_argument("--train-precision", choices=["f32", "bf16", "f16"], default="bf16")
     ap.add_argument("--stub", action="store_true",
                     help="launch-plumbing rehearsal without a GPU: the step is a no-op on CPU tensors and the line says so "
                          "(metric 'stub'); used by tests/test_dist_cpu.py with --backend gloo")
@@ -316,6 +318,45 @@ def main():
             del fm
         log(f"extras: {extras}")
 
+    # BASELINE config 3 (sub-record, every rank takes part): FCVSR-S training step - batch 32 clips sharded 8 x 4 (here: 4 clips
+    # of 7x128x128 -> 512x512 per rank, the reference's RandomCrop(128), train_LD_freqCVSR_S_22.py:187), Charbonnier-sum loss,
+    # Adam, ONE flat-buffer gradient all-reduce per step over RCCL.  Never part of `value`.
+    train = None
+    if not args.no_train and not args.stub:
+        try:
+            from fcvsr_amd.train import TrainStep
+            tm = A.GShiftNet_S()
+            tm.load_state_dict(synthetic_state_dict(state_dict_shapes("GShiftNet_S"), gain=0.5), strict=True)
+            tm = tm.to(dev)
+            tm.train_precision = args.train_precision
+            g = torch.Generator().manual_seed(300 + rank)                       # different data per rank, same weights
+            tx = torch.rand(4, 7, 1, 128, 128, generator=g).to(dev)
+            th = torch.rand(4, 1, 512, 512, generator=g).to(dev)
+            step = TrainStep(tm, lr=1e-4, weight_decay=1e-5)
+            step(tx, th)                                                         # warm-up (allocations, weight packing)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t1 = time.perf_counter()
+            nt = 3
+            for _ in range(nt):
+                lv = step(tx, th)
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev if world > 1 and args.backend == "nccl" else "cpu")
+            if world > 1:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sec = float(tt) / nt
+            train = {"workload": "FCVSR-S training step: 4 clips of 7x128x128 -> 512x512 per GPU, Charbonnier-sum, Adam, "
+                                 "flat f32 gradient all-reduce (SUM)", "world": world, "global_batch": 4 * world,
+                     "conv_precision": args.train_precision + (" forward/input-gradient on MFMA, f32 weight gradient" if args.train_precision != "f32" else " (exact)"),
+                     "ms_per_step": round(sec * 1e3, 2), "clips_per_s": round(4 * world / sec, 2),
+                     "allreduce_bytes": int(step.allreduce.numel * 4), "finite_loss": bool(np.isfinite(lv))}
+            log(f"train sub-record: {train}")
+            del tm, step, tx, th
+        except Exception as e:                                                   # a sub-record must never cost the headline line
+            train = {"error": repr(e)[:300]}
+            log(f"train sub-record failed: {e!r}")
+
     if rank == 0:
         line = {
             "metric": "SR frames/sec (7-frame window, 4x 180x320->720x1280) + PSNR vs ref", "value": round(fps, 3),
@@ -327,7 +368,7 @@ def main():
                        "parallelism": f"clip-dp{world}"},
             "frames_per_sec_per_gpu": round(fps / world, 3),
             "conv_tflops_end_to_end": round(fps * conv_flops_live(args.model, H, W) / 1e12, 3),
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "extras": extras,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "extras": extras, "train": train,
         }
         print(json.dumps(line))
     if world > 1:

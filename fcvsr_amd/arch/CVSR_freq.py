@@ -251,3 +251,29 @@ class GShiftNet(_GShiftBase):
 
     def __init__(self, n_features=64, wiF=1.5, AC_Ks=3, ACNum=6, Freq_Inv=8, SCGroupN=10):
         super().__init__(n_features, wiF, AC_Ks, ACNum, Freq_Inv, SCGroupN)
+
+
+class GShiftNet_ETC(GShiftNet):
+    """Multi-window variant (reference CVSR_freq.py:2760-2843): the input holds 13 frames, the network of ``GShiftNet`` (same
+    parameters and state_dict keys) super-resolves the 7 windows ``x[:, i:i+7]`` and returns
+    ``(out_seq, x_up)``, both ``(B, 7, C, 4H, 4W)``: the SR frames and the bilinear x4 bases of the window centres.
+    The windows are independent, so they are stacked on the batch axis and run as ONE forward instead of the reference's loop."""
+    _windows = 7
+
+    def forward(self, x: torch.Tensor):
+        if x.dim() != 5 or x.shape[1] != self._in_frames + self._windows - 1 or x.shape[2] != self._img_ch:
+            raise ValueError(f"expected (B,{self._in_frames + self._windows - 1},{self._img_ch},H,W) input, got {tuple(x.shape)}")
+        B, _, C, H, W = x.shape
+        T, Wn = self._in_frames, self._windows
+        win = torch.stack([x[:, i:i + T] for i in range(Wn)], 1).reshape(B * Wn, T, C, H, W)
+        out = super().forward(win).reshape(B, Wn, C, 4 * H, 4 * W)
+        if not x.is_cuda:
+            raise RuntimeError("fcvsr_amd runs on MI355X only (there is no CPU fallback)")
+        # x_up: bilinear x4 (align_corners=False) of the window centres, frames 3..9, by the same kernel as the global skip
+        import ctypes as C_
+        from .. import hip
+        centres = x[:, T // 2:T // 2 + Wn].reshape(B * Wn, C, H, W).float().contiguous()
+        base = torch.empty((B * Wn, C, 4 * H, 4 * W), dtype=torch.float32, device=x.device)
+        cv, ov = hip.view(centres.permute(0, 2, 3, 1)), hip.view(base.permute(0, 2, 3, 1))
+        hip.check(hip.lib().fcvsr_bilinear_up4(C_.byref(cv), B * Wn, H, W, C_.byref(ov), hip.stream_ptr()), "fcvsr_bilinear_up4")
+        return out, base.reshape(B, Wn, C, 4 * H, 4 * W)

@@ -33,7 +33,7 @@ def _run_conv(x_nhwc: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     out = torch.empty((B, Ho, Wo, cout), dtype=torch.float32, device=x_nhwc.device)
     b = None if bias is None else bias.detach().float().contiguous()
-    if precision in _MMA and k in (1, 3) and stride == 1 and cin % 4 == 0:
+    if precision in _MMA and k in (1, 3) and stride == 1 and cin % 4 == 0 and cout % 4 == 0:
         mdt, tdt = _MMA[precision]
         groups = [dict(srcs=[x_nhwc], dst=out)]
         if hip.mfma_eligible(k, stride, groups):

@@ -59,7 +59,12 @@ class FlatGradAllReduce:
             else:
                 v.copy_(p.grad.reshape(-1))
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)       # backend "nccl" is RCCL on ROCm
+            if flat.is_cuda and dist.get_backend(self.group) == "gloo":         # CPU rehearsals of the N>1 path
+                host = flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                flat.copy_(host)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)   # backend "nccl" is RCCL on ROCm
             if self.op == "mean":
                 flat.div_(dist.get_world_size(self.group))
         for v, p in zip(views, self.params):

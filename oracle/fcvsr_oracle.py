@@ -371,3 +371,14 @@ def forward(p: Params, x: Tensor, taps: Optional[dict] = None) -> Tensor:
         taps["fz"] = fz
         taps["out"] = out + base
     return out + base
+
+
+def forward_etc(p: Params, x: Tensor) -> Tuple[Tensor, Tensor]:
+    """GShiftNet_ETC (CVSR_freq.py:2760-2843): x (B,13,C,H,W) -> (out_seq, x_up), both (B,7,C,4H,4W): the network of
+    ``forward`` on the 7 windows x[:, i:i+7] and the bilinear x4 bases of their centre frames."""
+    outs, ups = [], []
+    for i in range(7):
+        sub = x[:, i:i + 7]
+        outs.append(forward(p, sub))
+        ups.append(F.interpolate(sub[:, 3], scale_factor=4, mode="bilinear", align_corners=False))
+    return torch.stack(outs, 1), torch.stack(ups, 1)

@@ -151,6 +151,21 @@ def run_case(ref, name, ctor, kwargs, x, tap_filter=None):
     return shapes
 
 
+def run_etc(ref, name, x):
+    """GShiftNet_ETC (CVSR_freq.py:2760-2843): 13 frames in, (out_seq, x_up) out; default full-size configuration."""
+    torch.manual_seed(0)
+    model = ref.GShiftNet_ETC()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(synthetic_state_dict(shapes, gain=0.5), strict=True)
+    with torch.no_grad():
+        out_seq, x_up = model(torch.from_numpy(x))
+    meta = dict(ctor="GShiftNet_ETC", kwargs={}, gain=0.5)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), x=x, **{"tap:out_seq": out_seq.numpy().astype(np.float32),
+                        "tap:x_up": x_up.numpy().astype(np.float32)}, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+    print(name, "out_seq", tuple(out_seq.shape), "mean/std", float(out_seq.mean()), float(out_seq.std()))
+    return shapes
+
+
 def main():
     ref = import_reference()
     rs = np.random.RandomState(1234)
@@ -163,6 +178,7 @@ def main():
              np.random.RandomState(0).rand(1, 7, 1, 64, 64).astype(np.float32), ("out", "mgaa2.out"))
     run_case(ref, "Sreduced_24x16", "GShiftNet_S", dict(n_features=32, ACNum=2, Freq_Inv=2, SCGroupN=1),
              rs.rand(1, 7, 1, 24, 16).astype(np.float32), small)
+    sE = run_etc(ref, "etc_12x16", np.random.RandomState(77).rand(1, 13, 1, 12, 16).astype(np.float32))
     rgb = import_reference_rgb()
     sRS = run_case(rgb["fcvsr_s.py"], "rgbS_16x20", "FCVSR_SNet", {}, rs.rand(1, 7, 3, 16, 20).astype(np.float32),
                    ("out", "mgaa2.out", "sc.o2", "fz", "feat"))
@@ -171,6 +187,7 @@ def main():
     with open(os.path.join(HERE, "schema.json"), "w") as f:
         json.dump({"GShiftNet_S": {k: list(v) for k, v in sS.items()},
                    "GShiftNet": {k: list(v) for k, v in sF.items()},
+                   "GShiftNet_ETC": {k: list(v) for k, v in sE.items()},
                    "FCVSR_SNet": {k: list(v) for k, v in sRS.items()},
                    "FCVSRNet": {k: list(v) for k, v in sRF.items()}}, f, indent=0)
 

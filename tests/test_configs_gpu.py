@@ -116,3 +116,42 @@ def test_config1_timed_configuration_b16_streams4_graph():
         for b in (0, 5, 15):
             yb = model(x[b:b + 1])
             assert torch.equal(yb[0], y[b]), b
+
+
+def test_config4_full_model_reds4_shaped_streamed_over_two_ranks():
+    """BASELINE config 4/5: the FULL model (GShiftNet: A=6, Q=8, G=10, 3x3 up-convs) on REDS4-shaped sequences (4 x 100 LR frames of
+    180x320, anna_file/REDS4_GT.txt) streamed through the clip scheduler, sharded over two ranks.
+    (i) exact-f32 mode within 1e-4 of the CPU oracle on a window at the real size; (ii) the streamed bf16 run covers every
+    frame once, equals the per-sequence harness on sampled frames and stays beyond 60 dB PSNR of the f32 oracle frame."""
+    from fcvsr_amd.arch.CVSR_freq import GShiftNet
+    from fcvsr_amd.arch.schema import state_dict_shapes
+    from fcvsr_amd.harness.infer import StreamedSuperResolver, super_resolve_sequence
+    from fcvsr_amd.harness.windows import window_indices
+    from fcvsr_amd.weights import synthetic_state_dict
+    from oracle import fcvsr_oracle as O
+    sd = synthetic_state_dict(state_dict_shapes("GShiftNet"), gain=0.5)
+    model = GShiftNet()
+    model.load_state_dict(sd)
+    model = model.cuda()
+    seqs = [_smooth_video(100, 180, 320, seed=40 + s) for s in range(4)]
+    win = torch.stack([seqs[1][j] for j in window_indices(98, 7, 100)], 0)[None]          # replicate padding at the sequence end
+    with torch.no_grad():
+        ref = O.forward(sd, win)
+        model.precision = "f32"
+        y32 = model(win.cuda()).cpu()
+    assert float((y32 - ref).abs().max()) <= 1e-4
+    model.precision = "bf16"
+    model.streams = 2
+    got = {s: np.zeros((100, 1, 720, 1280), dtype=np.uint8) for s in range(4)}
+    seen = {s: np.zeros(100, dtype=np.int32) for s in range(4)}
+    for rank in range(2):
+        for s, (first, arr) in StreamedSuperResolver(model, batch=8).run(seqs, rank=rank, world=2).items():
+            got[s][first:first + len(arr)] = arr
+            seen[s][first:first + len(arr)] += 1
+    assert all((seen[s] == 1).all() for s in range(4))
+    sample = super_resolve_sequence(model, seqs[1], batch=3, centres=[0, 49, 98])
+    d = np.abs(sample.astype(np.int32) - got[1][[0, 49, 98]].astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3                   # batch composition only moves values on an integer boundary
+    ref_u8 = (ref.clamp(0, 1) * 255.0).numpy()[0]
+    mse = float(((got[1][98].astype(np.float64) - ref_u8) ** 2).mean())
+    assert 20 * np.log10(255 / np.sqrt(mse)) >= 45.0                # uint8 truncation of the harness bounds this (~ 51 dB for exact values)

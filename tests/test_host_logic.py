@@ -13,7 +13,7 @@ from helpers import GOLDEN_DIR, load_schema
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-@pytest.mark.parametrize("ctor", ["GShiftNet_S", "GShiftNet", "FCVSR_SNet", "FCVSRNet"])
+@pytest.mark.parametrize("ctor", ["GShiftNet_S", "GShiftNet", "GShiftNet_ETC", "FCVSR_SNet", "FCVSRNet"])
 def test_state_dict_schema_matches_reference(ctor):
     from fcvsr_amd.arch.schema import state_dict_shapes
     ref = {k: tuple(v) for k, v in load_schema()[ctor].items()}

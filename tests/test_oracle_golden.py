@@ -28,6 +28,16 @@ def test_oracle_matches_reference_taps(name):
     assert float((y - gold["out"]).abs().max()) <= 1e-5
 
 
+def test_oracle_etc_matches_reference():
+    """GShiftNet_ETC (13 frames -> 7 SR frames + 7 bilinear bases) against the reference's own output (etc_12x16.npz)."""
+    x, gold, meta = load_case("etc_12x16")
+    with torch.no_grad():
+        out_seq, x_up = O.forward_etc(weights_for(meta), x)
+    assert out_seq.shape == gold["out_seq"].shape and x_up.shape == gold["x_up"].shape
+    assert float((out_seq - gold["out_seq"]).abs().max()) <= 1e-5
+    assert float((x_up - gold["x_up"]).abs().max()) <= 1e-6
+
+
 def test_psnr_constants():
     """Known-answer PSNR values the reference's own tests hold (mmedit_train/tests/test_metrics/test_metrics.py:31-71)."""
     import numpy as np

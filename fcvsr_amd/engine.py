@@ -134,6 +134,8 @@ class Engine:
                 b = b[rows[0]:rows[1]].contiguous() if b is not None else None
             if kind == "direct":
                 pk = hip.pack_conv_weight(w)
+            elif kind == "f32mfma":
+                pk = hip.pack_conv_weight_f32mfma(w)
             else:
                 pk = hip.pack_conv_weight_mfma(w, kind, ps=ps)
                 if ps and b is not None:
@@ -216,9 +218,15 @@ class Engine:
                             name=name)
             return True
         w, b, cout, _ = self._weights(name, "direct", False, rows, cols)
+        # exact f32 on the matrix cores (v_mfma_f32_32x32x2_f32) for the 3x3 / 1x1 stride-1 layers with a dense source of a
+        # multiple of 32 channels; the direct VALU kernel for the rest (skinny / strided / concatenated / pixel-shuffled layers)
+        wm = None
+        if (ksz in (1, 3) and stride == 1 and not ps and not direct and all(len(g["srcs"]) == 1 and g["srcs"][0].shape[3] % 32 == 0
+                                                                             for g in groups)):
+            wm = self._weights(name, "f32mfma", False, rows, cols)[0]
         for g in groups:
             hip.conv2d(g["srcs"], w, ksz, cout, g["dst"], bias=b, stride=stride, act=act, slope=slope, slope_t=slope_t,
-                       res=g.get("res", ()), res_scale=res_scale, pixel_shuffle=ps, name=name)
+                       res=g.get("res", ()), res_scale=res_scale, pixel_shuffle=ps, name=name, w_f32mfma=wm)
         return False
 
     def _tap(self, name, t_nhwc):

@@ -74,6 +74,8 @@ SIGNATURES = {
     "fcvsr_abi_version": [],
     "fcvsr_device_count": [],
     "fcvsr_conv2d": [C.POINTER(ConvDesc), _VP],
+    "fcvsr_conv2d_f32mfma": [C.POINTER(ConvDesc), _VP],
+    "fcvsr_conv2d_f32mfma_eligible": [C.POINTER(ConvDesc)],
     "fcvsr_conv2d_mfma": [C.POINTER(ConvDesc), _I, _I, _VP],
     "fcvsr_rfft2": [_PV, _I, _I, _I, _I, _VP, _I64, _I, _I, _VP],
     "fcvsr_irfft2": [_VP, _I64, _I, _I, _I, _I, _I, _I, _VP, _VP, _PV, _VP],
@@ -153,6 +155,15 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     cp = (cout + 15) // 16 * 16
     out = torch.zeros(kh * kw, cin, cp, dtype=torch.float32, device=w.device)
     out[:, :, :cout] = w.detach().float().permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)
+    return out.contiguous()
+
+
+def pack_conv_weight_f32mfma(w: torch.Tensor) -> torch.Tensor:
+    """(Cout, Cin, kh, kw) -> f32 [kh*kw][ceil64(Cout)][Cin] (layout of fcvsr_conv2d_f32mfma), zero rows past Cout."""
+    cout, cin, kh, kw = w.shape
+    cop = (cout + 63) // 64 * 64
+    out = torch.zeros(kh * kw, cop, cin, dtype=torch.float32, device=w.device)
+    out[:, :cout] = w.detach().float().permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)
     return out.contiguous()
 
 
@@ -251,11 +262,23 @@ def conv2d_mfma(groups, wpacked: torch.Tensor, ksize: int, cout: int, mma_dtype:
     check(lib().fcvsr_conv2d_mfma(descs, n, mma_dtype, stream_ptr()), "fcvsr_conv2d_mfma")
 
 
+F32_MFMA = os.environ.get("FCVSR_F32_MFMA", "1") == "1"     # exact-f32 layers on the matrix cores where eligible
+
+
 def conv2d(srcs: Sequence[torch.Tensor], wpacked: torch.Tensor, ksize: int, cout: int, dst: torch.Tensor, *,
            bias: Optional[torch.Tensor] = None, stride: int = 1, act: int = ACT_NONE, slope: float = 0.0,
            slope_t: Optional[torch.Tensor] = None, res: Sequence[torch.Tensor] = (),
-           res_scale: Sequence[float] = (), pixel_shuffle: bool = False, name: str = "") -> torch.Tensor:
-    """srcs / res / dst are (b,y,x,c)-ordered tensors (any strides)."""
+           res_scale: Sequence[float] = (), pixel_shuffle: bool = False, name: str = "",
+           w_f32mfma: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """srcs / res / dst are (b,y,x,c)-ordered tensors (any strides).  Exact f32: the direct VALU kernel, or - when
+    `w_f32mfma` (pack_conv_weight_f32mfma) is given and the layer qualifies - the f32-operand matrix-core kernel."""
+    if w_f32mfma is not None and F32_MFMA and len(srcs) == 1 and stride == 1 and not pixel_shuffle and PROFILE is None:
+        dm = ConvDesc()
+        _fill_desc(dm, srcs, w_f32mfma, ksize, cout, w_f32mfma.shape[1], dst, bias, stride, act, slope, slope_t, res, res_scale,
+                   pixel_shuffle)
+        if lib().fcvsr_conv2d_f32mfma_eligible(C.byref(dm)):
+            check(lib().fcvsr_conv2d_f32mfma(C.byref(dm), stream_ptr()), "fcvsr_conv2d_f32mfma")
+            return dst
     d = ConvDesc()
     cin = _fill_desc(d, srcs, wpacked, ksize, cout, wpacked.shape[-1], dst, bias, stride, act, slope, slope_t, res,
                      res_scale, pixel_shuffle)

@@ -39,7 +39,8 @@ def _run_conv(x_nhwc: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
         if hip.mfma_eligible(k, stride, groups):
             hip.conv2d_mfma(groups, hip.pack_conv_weight_mfma(w, tdt), k, cout, mdt, bias=b)
             return out
-    hip.conv2d([x_nhwc], hip.pack_conv_weight(w), k, cout, out, bias=b, stride=stride)
+    wm = hip.pack_conv_weight_f32mfma(w) if (k in (1, 3) and stride == 1 and cin % 32 == 0 and cout % 4 == 0) else None
+    hip.conv2d([x_nhwc], hip.pack_conv_weight(w), k, cout, out, bias=b, stride=stride, w_f32mfma=wm)
     return out
 
 

@@ -91,6 +91,12 @@ int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int mma_dtype,
 /* Name (template instance) of the kernel the calling thread's last fcvsr_conv2d_mfma call launched, e.g.
  * "conv3_res_kernel<true, true, 1>": measurement aid for bench.py's per-kernel roofline, not part of the data path. */
 const char* fcvsr_last_conv_kernel(void);
+/* fcvsr_conv2d on the matrix cores with f32 operands (v_mfma_f32_32x32x2_f32: exact f32, bit-equal to an fmaf chain): the
+ * arithmetic of the exact-f32 mode for 3x3 / 1x1 stride-1 layers with one dense NHWC f32 source of a multiple of 32 channels,
+ * no pixel shuffle.  weight: f32 [kh*kw][cout_pad][cin], cout_pad a multiple of 64 (zero rows past cout); every other field as
+ * in fcvsr_conv2d.  fcvsr_conv2d_f32mfma_eligible returns 1 when the descriptor qualifies. */
+int fcvsr_conv2d_f32mfma_eligible(const fcvsr_conv_desc* d);
+int fcvsr_conv2d_f32mfma(const fcvsr_conv_desc* d, void* stream);
 /* Backward of the convolutions (reference: `loss.backward()` through nn.Conv2d, CVSR_train/train_LD_freqCVSR_S_22.py:250).
  * The input gradient of a stride-1 "same" convolution is itself such a convolution of the output gradient with the transposed,
  * tap-flipped weight, so it goes through fcvsr_conv2d / fcvsr_conv2d_mfma; the weight gradient is this entry point:

@@ -494,3 +494,31 @@ def test_freq_head_matches_separate_1x1_launches(nhid, src):
                                 pl.data_ptr(), out.data_ptr(), hip.stream_ptr()), "freq_head")
     torch.cuda.synchronize()
     assert float((out - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("cin,cout,k,H,W,nres,act", [(64, 64, 3, 21, 37, 0, "leaky"), (128, 64, 3, 18, 70, 2, "none"), (64, 1152, 1, 13, 29, 0, "none"),
+                                                    (32, 36, 1, 9, 17, 1, "relu"), (64, 128, 3, 40, 33, 1, "prelu")])
+def test_conv_f32_matrix_core_kernel_equals_direct_kernel(cin, cout, k, H, W, nres, act):
+    """fcvsr_conv2d_f32mfma (v_mfma_f32_32x32x2_f32, exact f32 products and sums) against the direct VALU kernel on the same
+    layer: only the summation order differs (tolerance 2e-6 of the output scale), incl. partial tiles, bias, every activation
+    and two scaled residuals."""
+    from fcvsr_amd import hip
+    g0 = torch.Generator().manual_seed(cin + cout + k)
+    w = (torch.randn(cout, cin, k, k, generator=g0) / (cin * k * k) ** 0.5).cuda()
+    bias = torch.randn(cout, generator=g0).cuda()
+    x = torch.randn(2, H, W, cin, generator=g0).cuda()
+    res = [torch.randn(2, H, W, cout, generator=g0).cuda() for _ in range(nres)]
+    slope_t = torch.tensor([0.3]).cuda()
+    a = {"leaky": hip.ACT_LEAKY, "none": hip.ACT_NONE, "relu": hip.ACT_RELU, "prelu": hip.ACT_PRELU}[act]
+    kw = dict(bias=bias, act=a, slope=0.1, slope_t=slope_t if act == "prelu" else None, res=res, res_scale=[1.0, -0.5][:nres])
+    wd, wm = hip.pack_conv_weight(w), hip.pack_conv_weight_f32mfma(w)
+    y_d = hip.conv2d([x], wd, k, cout, torch.empty(2, H, W, cout, device="cuda"), **kw).clone()
+    y_m = torch.full((2, H, W, cout), float("nan"), device="cuda")
+    d = hip.ConvDesc()
+    hip._fill_desc(d, [x], wm, k, cout, wm.shape[1], y_m, bias, 1, a, 0.1, kw["slope_t"], res, kw["res_scale"], False)
+    import ctypes as C
+    assert hip.lib().fcvsr_conv2d_f32mfma_eligible(C.byref(d)) == 1
+    hip.conv2d([x], wd, k, cout, y_m, w_f32mfma=wm, **kw)
+    torch.cuda.synchronize()
+    assert not torch.isnan(y_m).any()
+    assert float((y_m - y_d).abs().max()) <= 2e-6 * max(1.0, float(y_d.abs().max()))

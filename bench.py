@@ -235,7 +235,7 @@ def main():
                 pm = json.load(f)
             c = pm["config"]
             if (c["model"], c["batch"], c["precision"], c["height"], c["width"], c.get("act16", False)) == \
-                    (args.model, B, args.precision, H, W, bool(args.trunk16)) and var == pm.get("kernel", "").replace("void fcvsr::", ""):
+                    (args.model, B, args.precision, H, W, bool(args.trunk16)) and pm.get("kernel", "").replace("void fcvsr::", "").startswith(var.rstrip(">")):
                 traffic = round(pm["hbm_bytes_per_launch"])
         except Exception:
             traffic = None

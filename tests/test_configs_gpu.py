@@ -95,7 +95,8 @@ def test_config1_bench_shape_against_oracle():
             assert 10 * np.log10(1 + 10 ** ((30.0 - psnr) / 10)) < 0.01
 
 
-def test_config1_timed_configuration_b16_streams4_graph():
+@pytest.mark.parametrize("ns", [2, 4])
+def test_config1_timed_configuration_b16_streams_graph(ns):
     """What bench.py times - batch 16, 4 HIP streams, hipGraph replay, bf16 operands, 16-bit activation storage, 180x320 -
     equals, bit for bit, the eager single-stream forward of each clip on its own (B = 1): clips are independent and every
     reduction of the path has a fixed order that does not depend on the batch a clip travels in."""
@@ -108,7 +109,7 @@ def test_config1_timed_configuration_b16_streams4_graph():
     model.precision = "bf16"
     x = torch.from_numpy(np.random.RandomState(1).rand(16, 7, 1, 180, 320).astype(np.float32)).cuda()
     with torch.no_grad():
-        model.streams, model.use_graph = 4, True
+        model.streams, model.use_graph = ns, True
         y = model(x).clone()
         y_replay = model(x).clone()
         assert torch.equal(y, y_replay)

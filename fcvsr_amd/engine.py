@@ -135,7 +135,9 @@ class Engine:
             if kind == "direct":
                 pk = hip.pack_conv_weight(w)
             elif kind == "f32mfma":
-                pk = hip.pack_conv_weight_f32mfma(w)
+                pk = hip.pack_conv_weight_f32mfma(w, ps=ps)
+                if ps and b is not None:
+                    b = b[hip.ps_order(w.shape[0]).to(b.device)].contiguous()
             else:
                 pk = hip.pack_conv_weight_mfma(w, kind, ps=ps)
                 if ps and b is not None:
@@ -220,13 +222,13 @@ class Engine:
         w, b, cout, _ = self._weights(name, "direct", False, rows, cols)
         # exact f32 on the matrix cores (v_mfma_f32_32x32x2_f32) for the 3x3 / 1x1 stride-1 layers with a dense source of a
         # multiple of 32 channels; the direct VALU kernel for the rest (skinny / strided / concatenated / pixel-shuffled layers)
-        wm = None
-        if (ksz in (1, 3) and stride == 1 and not ps and not direct and all(len(g["srcs"]) == 1 and g["srcs"][0].shape[3] % 32 == 0
-                                                                             for g in groups)):
-            wm = self._weights(name, "f32mfma", False, rows, cols)[0]
+        wm = bm = None
+        if (ksz in (1, 3) and stride == 1 and not direct and all(len(g["srcs"]) == 1 and g["srcs"][0].shape[3] % 32 == 0
+                                                                  for g in groups) and (not ps or cout % 16 == 0)):
+            wm, bm = self._weights(name, "f32mfma", ps, rows, cols)[:2]
         for g in groups:
             hip.conv2d(g["srcs"], w, ksz, cout, g["dst"], bias=b, stride=stride, act=act, slope=slope, slope_t=slope_t,
-                       res=g.get("res", ()), res_scale=res_scale, pixel_shuffle=ps, name=name, w_f32mfma=wm)
+                       res=g.get("res", ()), res_scale=res_scale, pixel_shuffle=ps, name=name, w_f32mfma=wm, bias_f32mfma=bm)
         return False
 
     def _tap(self, name, t_nhwc):

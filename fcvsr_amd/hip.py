@@ -158,8 +158,11 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     return out.contiguous()
 
 
-def pack_conv_weight_f32mfma(w: torch.Tensor) -> torch.Tensor:
-    """(Cout, Cin, kh, kw) -> f32 [kh*kw][ceil64(Cout)][Cin] (layout of fcvsr_conv2d_f32mfma), zero rows past Cout."""
+def pack_conv_weight_f32mfma(w: torch.Tensor, ps: bool = False) -> torch.Tensor:
+    """(Cout, Cin, kh, kw) -> f32 [kh*kw][ceil64(Cout)][Cin] (layout of fcvsr_conv2d_f32mfma), zero rows past Cout; with
+    ps=True the rows are in the sub-pixel-major order of the pixel-shuffle epilogue (`ps_order`)."""
+    if ps:
+        w = w[ps_order(w.shape[0]).to(w.device)]
     cout, cin, kh, kw = w.shape
     cop = (cout + 63) // 64 * 64
     out = torch.zeros(kh * kw, cop, cin, dtype=torch.float32, device=w.device)
@@ -269,13 +272,13 @@ def conv2d(srcs: Sequence[torch.Tensor], wpacked: torch.Tensor, ksize: int, cout
            bias: Optional[torch.Tensor] = None, stride: int = 1, act: int = ACT_NONE, slope: float = 0.0,
            slope_t: Optional[torch.Tensor] = None, res: Sequence[torch.Tensor] = (),
            res_scale: Sequence[float] = (), pixel_shuffle: bool = False, name: str = "",
-           w_f32mfma: Optional[torch.Tensor] = None) -> torch.Tensor:
+           w_f32mfma: Optional[torch.Tensor] = None, bias_f32mfma: Optional[torch.Tensor] = None) -> torch.Tensor:
     """srcs / res / dst are (b,y,x,c)-ordered tensors (any strides).  Exact f32: the direct VALU kernel, or - when
     `w_f32mfma` (pack_conv_weight_f32mfma) is given and the layer qualifies - the f32-operand matrix-core kernel."""
-    if w_f32mfma is not None and F32_MFMA and len(srcs) == 1 and stride == 1 and not pixel_shuffle and PROFILE is None:
-        dm = ConvDesc()
-        _fill_desc(dm, srcs, w_f32mfma, ksize, cout, w_f32mfma.shape[1], dst, bias, stride, act, slope, slope_t, res, res_scale,
-                   pixel_shuffle)
+    if w_f32mfma is not None and F32_MFMA and len(srcs) == 1 and stride == 1 and PROFILE is None:
+        dm = ConvDesc()              # (pixel-shuffled layers: w_f32mfma / bias_f32mfma are in sub-pixel-major row order)
+        _fill_desc(dm, srcs, w_f32mfma, ksize, cout, w_f32mfma.shape[1], dst, bias_f32mfma if pixel_shuffle else bias, stride, act,
+                   slope, slope_t, res, res_scale, pixel_shuffle)
         if lib().fcvsr_conv2d_f32mfma_eligible(C.byref(dm)):
             check(lib().fcvsr_conv2d_f32mfma(C.byref(dm), stream_ptr()), "fcvsr_conv2d_f32mfma")
             return dst

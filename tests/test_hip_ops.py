@@ -522,3 +522,36 @@ def test_conv_f32_matrix_core_kernel_equals_direct_kernel(cin, cout, k, H, W, nr
     torch.cuda.synchronize()
     assert not torch.isnan(y_m).any()
     assert float((y_m - y_d).abs().max()) <= 2e-6 * max(1.0, float(y_d.abs().max()))
+
+
+def test_conv_f32_matrix_core_pixel_shuffle_and_skinny_outputs():
+    """The two remaining heavy layers of the exact-f32 up-sampler on the f32-operand matrix-core kernel: a 1x1 64->256 layer with
+    PReLU and PixelShuffle(2) store (sub-pixel-major packed rows) and the 3x3 64->C_img layer that adds into the NCHW result
+    (scalar epilogue, strided destination, residual = destination), both against the direct kernel."""
+    from fcvsr_amd import hip
+    g0 = torch.Generator().manual_seed(9)
+    B, H, W = 2, 10, 37
+    x = torch.randn(B, H, W, 64, generator=g0).cuda()
+    slope_t = torch.tensor([0.25]).cuda()
+    for k in (1, 3):
+        w = (torch.randn(256, 64, k, k, generator=g0) / (64 * k * k) ** 0.5).cuda()
+        bias = torch.randn(256, generator=g0).cuda()
+        y_d = hip.conv2d([x], hip.pack_conv_weight(w), k, 256, torch.empty(B, 2 * H, 2 * W, 64, device="cuda"), bias=bias,
+                         act=hip.ACT_PRELU, slope_t=slope_t, pixel_shuffle=True).clone()
+        y_m = torch.full((B, 2 * H, 2 * W, 64), float("nan"), device="cuda")
+        hip.conv2d([x], hip.pack_conv_weight(w), k, 256, y_m, bias=bias, act=hip.ACT_PRELU, slope_t=slope_t, pixel_shuffle=True,
+                   w_f32mfma=hip.pack_conv_weight_f32mfma(w, ps=True), bias_f32mfma=bias[hip.ps_order(256).cuda()].contiguous())
+        torch.cuda.synchronize()
+        assert not torch.isnan(y_m).any()
+        assert float((y_m - y_d).abs().max()) <= 2e-6 * max(1.0, float(y_d.abs().max()))
+    for cimg in (1, 3):
+        w = (torch.randn(cimg, 64, 3, 3, generator=g0) / 24.0).cuda()
+        bias = torch.randn(cimg, generator=g0).cuda()
+        base = torch.randn(B, cimg, H, W, generator=g0).cuda()
+        out_d, out_m = base.clone(), base.clone()
+        for out, wm in ((out_d, None), (out_m, hip.pack_conv_weight_f32mfma(w))):
+            ov = out.permute(0, 2, 3, 1)
+            hip.conv2d([x], hip.pack_conv_weight(w), 3, cimg, ov, bias=bias, res=[ov], w_f32mfma=wm)
+        torch.cuda.synchronize()
+        assert float((out_m - out_d).abs().max()) <= 2e-6 * max(1.0, float(out_d.abs().max()))
+        assert float((out_d - base).abs().max()) > 0.1

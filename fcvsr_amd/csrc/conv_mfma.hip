@@ -93,8 +93,7 @@ __device__ __forceinline__ bool epilogue_quad(const EpiCtx& e, float4 v, const f
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    if (e.act == FCVSR_ACT_RELU) x[q] = fmaxf(x[q], 0.f);
-    else if (e.act == FCVSR_ACT_LEAKY || e.act == FCVSR_ACT_PRELU) x[q] = x[q] >= 0.f ? x[q] : x[q] * e.slope;
+    x[q] = x[q] >= 0.f ? x[q] : x[q] * e.slope;        // e.slope = negative-side factor: 0 (ReLU), the slope, or 1 (none) - no branch on act
   }
   // residual inputs are indexed by the ORIGINAL output channel: with pixel-shuffle packing row n = sp*(cout/4)+c is
   // original channel 4c+sp
@@ -175,8 +174,7 @@ __device__ __forceinline__ void epilogue_oct(const EpiCtx& e, float4 va, float4 
   }
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    if (e.act == FCVSR_ACT_RELU) x[q] = fmaxf(x[q], 0.f);
-    else if (e.act == FCVSR_ACT_LEAKY || e.act == FCVSR_ACT_PRELU) x[q] = x[q] >= 0.f ? x[q] : x[q] * e.slope;
+    x[q] = x[q] >= 0.f ? x[q] : x[q] * e.slope;        // e.slope = negative-side factor: 0 (ReLU), the slope, or 1 (none) - no branch on act
   }
 #pragma unroll
   for (int ri = 0; ri < 2; ++ri) {
@@ -448,9 +446,9 @@ __global__ __launch_bounds__(256, MW == 1 ? (WD ? (NT == 128 ? 2 : 3) : (NT == 1
   // bound, ~1 TB/s).  Through LDS each lane gets 4 consecutive couts of one pixel: bias / residual loads and the output
   // store are 16 bytes per lane and a wave instruction covers whole 256-byte runs of a pixel's channels.
   float slope = a.slope;
-  if (a.act == FCVSR_ACT_PRELU) slope = a.slope_ptr[0];
+  if (a.act == FCVSR_ACT_PRELU) slope = *reinterpret_cast<const __attribute__((address_space(1))) float*>(reinterpret_cast<uintptr_t>(a.slope_ptr));   // global, not flat: a flat_load turns every later counted lgkmcnt into lgkmcnt(0)
   EpiCtx e;
-  e.act = a.act; e.slope = slope; e.n_res = a.n_res; e.rs0 = a.rs[0]; e.rs1 = a.rs[1]; e.ps = a.ps; e.flat = a.flat;
+  e.act = a.act; e.slope = a.act == FCVSR_ACT_RELU ? 0.f : (a.act == FCVSR_ACT_NONE ? 1.f : slope); e.n_res = a.n_res; e.rs0 = a.rs[0]; e.rs1 = a.rs[1]; e.ps = a.ps; e.flat = a.flat;
   e.res0 = G.res[0]; e.res1 = G.res[1]; e.dst = G.dst; e.H = G.H; e.W = G.W; e.b = b; e.npix = npix;
   e.dst16 = a.dst16; e.dstbf = a.dstbf; e.cq4 = a.cout >> 2; e.sub2 = a.sub2;
   constexpr int EW = NT >= 64 ? 64 : 32;        // couts per pass
@@ -709,8 +707,9 @@ __global__ __launch_bounds__(256, NT == 128 ? 2 : 4) void conv3_lean_kernel(Mfma
 
   // ---- epilogue: one tile row per wave ---------------------------------------------------------------------------------
   float slope = a.slope;
-  if (a.act == FCVSR_ACT_PRELU) slope = a.slope_ptr[0];
+  if (a.act == FCVSR_ACT_PRELU) slope = *reinterpret_cast<const __attribute__((address_space(1))) float*>(reinterpret_cast<uintptr_t>(a.slope_ptr));   // global, not flat: a flat_load turns every later counted lgkmcnt into lgkmcnt(0)
   const int act = a.act;
+  const float nsf = act == FCVSR_ACT_RELU ? 0.f : (act == FCVSR_ACT_NONE ? 1.f : slope);   // negative-side factor of the activation
   constexpr int EW = NT >= 64 ? 64 : 32;
   constexpr int EROW = EW + 4;
   __syncthreads();
@@ -753,13 +752,8 @@ __global__ __launch_bounds__(256, NT == 128 ? 2 : 4) void conv3_lean_kernel(Mfma
           const float4 va = *reinterpret_cast<const float4*>(es + j * PPI * EROW);
           const float4 vb = *reinterpret_cast<const float4*>(es + j * PPI * EROW + 4);
           float x[8] = {va.x + b0.x, va.y + b0.y, va.z + b0.z, va.w + b0.w, vb.x + b1.x, vb.y + b1.y, vb.z + b1.z, vb.w + b1.w};
-          if (act == FCVSR_ACT_RELU) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) x[k] = fmaxf(x[k], 0.f);
-          } else if (act != FCVSR_ACT_NONE) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) x[k] = x[k] >= 0.f ? x[k] : x[k] * slope;
-          }
+          for (int k = 0; k < 8; ++k) x[k] = x[k] >= 0.f ? x[k] : x[k] * nsf;      // branch-free (hipcc does not unswitch on act)
           if (a.n_res > 0) {
             float rr[8];
             load_res<BF16, 8>(r0v.p, r0off + px * r0sx + n, r16, rr);
@@ -801,12 +795,8 @@ __global__ __launch_bounds__(256, NT == 128 ? 2 : 4) void conv3_lean_kernel(Mfma
         if (pval && nok) {
           const float4 va = *reinterpret_cast<const float4*>(es + j * PPI * EROW);
           x = make_float4(va.x + b0.x, va.y + b0.y, va.z + b0.z, va.w + b0.w);
-          if (act == FCVSR_ACT_RELU) {
-            x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f);
-          } else if (act != FCVSR_ACT_NONE) {
-            x.x = x.x >= 0.f ? x.x : x.x * slope; x.y = x.y >= 0.f ? x.y : x.y * slope;
-            x.z = x.z >= 0.f ? x.z : x.z * slope; x.w = x.w >= 0.f ? x.w : x.w * slope;
-          }
+          x.x = x.x >= 0.f ? x.x : x.x * nsf; x.y = x.y >= 0.f ? x.y : x.y * nsf;
+          x.z = x.z >= 0.f ? x.z : x.z * nsf; x.w = x.w >= 0.f ? x.w : x.w * nsf;
           if (vec) {
             if (a.n_res > 0) {
               float rr[4];
@@ -991,8 +981,9 @@ __global__ __launch_bounds__(256, 4) void conv1_lean_kernel(MfmaArgs a) {
   }
 
   float slope = a.slope;
-  if (a.act == FCVSR_ACT_PRELU) slope = a.slope_ptr[0];
+  if (a.act == FCVSR_ACT_PRELU) slope = *reinterpret_cast<const __attribute__((address_space(1))) float*>(reinterpret_cast<uintptr_t>(a.slope_ptr));   // global, not flat: a flat_load turns every later counted lgkmcnt into lgkmcnt(0)
   const int act = a.act;
+  const float nsf = act == FCVSR_ACT_RELU ? 0.f : (act == FCVSR_ACT_NONE ? 1.f : slope);   // negative-side factor of the activation
   constexpr int EW = NT >= 64 ? 64 : 32;
   constexpr int EROW = EW + 4;
   __syncthreads();
@@ -1038,13 +1029,8 @@ __global__ __launch_bounds__(256, 4) void conv1_lean_kernel(MfmaArgs a) {
         const float4 t = *reinterpret_cast<const float4*>(es + j * PPI * EROW + k);
         x[k] = t.x + bb[k]; x[k + 1] = t.y + bb[k + 1]; x[k + 2] = t.z + bb[k + 2]; x[k + 3] = t.w + bb[k + 3];
       }
-      if (act == FCVSR_ACT_RELU) {
 #pragma unroll
-        for (int k = 0; k < VPL; ++k) x[k] = fmaxf(x[k], 0.f);
-      } else if (act != FCVSR_ACT_NONE) {
-#pragma unroll
-        for (int k = 0; k < VPL; ++k) x[k] = x[k] >= 0.f ? x[k] : x[k] * slope;
-      }
+      for (int k = 0; k < VPL; ++k) x[k] = x[k] >= 0.f ? x[k] : x[k] * nsf;
       if (!PS) {
         if (a.n_res > 0) {
 #pragma unroll

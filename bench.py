@@ -348,7 +348,7 @@ def main():
             sec = float(tt) / nt
             train = {"workload": "FCVSR-S training step: 4 clips of 7x128x128 -> 512x512 per GPU, Charbonnier-sum, Adam, "
                                  "flat f32 gradient all-reduce (SUM)", "world": world, "global_batch": 4 * world,
-                     "conv_precision": args.train_precision + (" forward/input-gradient on MFMA, f32 weight gradient" if args.train_precision != "f32" else " (exact)"),
+                     "conv_precision": args.train_precision + (" forward / input-gradient / weight-gradient on MFMA (f32 accumulate)" if args.train_precision != "f32" else " (exact)"),
                      "ms_per_step": round(sec * 1e3, 2), "clips_per_s": round(4 * world / sec, 2),
                      "allreduce_bytes": int(step.allreduce.numel * 4), "finite_loss": bool(np.isfinite(lv))}
             log(f"train sub-record: {train}")

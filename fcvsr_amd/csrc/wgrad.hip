@@ -147,3 +147,186 @@ extern "C" int fcvsr_conv2d_wgrad(const fcvsr_view* x, const fcvsr_view* gy, int
   FCVSR_LAUNCH_CHECK();
   return 0;
 }
+
+// =====================================================================================================================
+// Matrix-core weight gradient (16-bit operands, f32 accumulate): the throughput path of the training step for the 3x3 / 1x1
+// stride-1 layers with multiples of 64 channels (SCNetbk bodies, conv_KP, F, conv3, recorb0: ~95 % of the weight-gradient FLOPs).
+//
+//   dW[tap][co][ci] = sum_p gy[p][co] * x[p + tap][ci]   =  per tap a (64 x K) x (K x 64) GEMM with K = pixels
+//
+// The reduction runs over PIXELS, but NHWC keeps channels contiguous, so both MFMA operands (8 consecutive k per lane) need the
+// transposed image.  A workgroup transposes while staging: f32 -> bf16, ds_write_b16 into [channel][row][x] LDS images whose
+// channel pitch is padded by 16 bytes (conflict-free ds_read_b128 over 32 channels).  A tap's horizontal shift would misalign the
+// 16-byte fragment reads, so the input tile is stored three times, pre-shifted by kx - 1; vertical shifts are row offsets.
+//   * workgroup = 256 threads = 4 waves = the 2 x 2 (cout, cin) fragment pairs of a 64 x 64 block, all 9 taps each: 9 f32
+//     accumulator fragments per wave (144 VGPRs) that persist over the workgroup's whole slab of 4 x 32 pixel tiles;
+//   * per 16-pixel k-step: 1 + 9 ds_read_b128 feed 9 MFMAs;
+//   * partial sums per slab go to the same scratch layout as the exact kernel and are added in slab order by
+//     wgrad_reduce_kernel: deterministic, no atomics.
+#include "mfma_util.h"
+
+namespace fcvsr {
+
+constexpr int kGTY = 4, kGTX = 32;
+constexpr int kGyPitch = kGTY * kGTX * 2 + 16;          // bytes per cout row of the gy^T image (4 rows x 32 px bf16 + pad)
+
+template <int KS>
+__global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(WgradArgs a, int tiles_x, int tiles_y, int tiles_per_slab) {
+  constexpr int PAD = KS / 2, HY = kGTY + 2 * PAD, NKX = KS;
+  constexpr int kXPitch = HY * kGTX * 2 + 16;           // bytes per cin row of one pre-shifted x^T image
+  extern __shared__ __align__(16) unsigned char lds[];
+  unsigned char* gy_s = lds;                             // [64 co][kGyPitch]
+  unsigned char* x_s = lds + 64 * kGyPitch;              // [NKX][64 ci][kXPitch]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int mf = wave >> 1, nf = wave & 1;               // this wave's (cout, cin) fragment pair
+  const int nci = a.cin / 64;
+  const int co0 = (blockIdx.y / nci) * 64, ci0 = (blockIdx.y % nci) * 64;
+  const int slab = blockIdx.x;
+  const int total_tiles = a.B * tiles_x * tiles_y;
+  const int t_begin = slab * tiles_per_slab;
+  int t_end = t_begin + tiles_per_slab;
+  if (t_end > total_tiles) t_end = total_tiles;
+
+  f32x16_t acc[KS * KS];
+#pragma unroll
+  for (int t = 0; t < KS * KS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int b = tile / (tiles_x * tiles_y);
+    const int t2 = tile - b * tiles_x * tiles_y;
+    const int ty0 = (t2 / tiles_x) * kGTY, tx0 = (t2 % tiles_x) * kGTX;
+    __syncthreads();                                     // the previous tile's images are no longer read
+    // ---- gy tile -> gy^T image: thread = (pixel, 4-cout quad), 16 quads per pixel, 16 pixels per pass -----------------------
+    {
+      const int q = tid & 15, p0 = tid >> 4;
+      for (int p = p0; p < kGTY * kGTX; p += 16) {
+        const int y = p >> 5, x = p & 31;
+        const int gyy = ty0 + y, gxx = tx0 + x;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gyy < a.Ho && gxx < a.Wo)
+          v = *reinterpret_cast<const float4*>(a.gy.p + (long long)b * a.gy.sb + (long long)gyy * a.gy.sy + (long long)gxx * a.gy.sx + co0 + q * 4);
+        const uint2 pk = cvt4<true>(v);
+        unsigned char* d = gy_s + (q * 4) * kGyPitch + (y * kGTX + x) * 2;
+        *reinterpret_cast<uint16_t*>(d) = (uint16_t)(pk.x & 0xffff);
+        *reinterpret_cast<uint16_t*>(d + kGyPitch) = (uint16_t)(pk.x >> 16);
+        *reinterpret_cast<uint16_t*>(d + 2 * kGyPitch) = (uint16_t)(pk.y & 0xffff);
+        *reinterpret_cast<uint16_t*>(d + 3 * kGyPitch) = (uint16_t)(pk.y >> 16);
+      }
+    }
+    // ---- x halo tile -> NKX pre-shifted x^T images: image kx holds x[.., tx0 + xx + kx - PAD] at column xx ---------------------
+    {
+      constexpr int HXW = kGTX + 2 * PAD;                // halo width
+      const int q = tid & 15, p0 = tid >> 4;
+      for (int p = p0; p < HY * HXW; p += 16) {
+        const int hy = p / HXW, hx = p - hy * HXW;
+        const int iy = ty0 + hy - PAD, ix = tx0 + hx - PAD;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+          v = *reinterpret_cast<const float4*>(a.x.p + (long long)b * a.x.sb + (long long)iy * a.x.sy + (long long)ix * a.x.sx + ci0 + q * 4);
+        const uint2 pk = cvt4<true>(v);
+        const uint16_t e0 = (uint16_t)(pk.x & 0xffff), e1 = (uint16_t)(pk.x >> 16), e2 = (uint16_t)(pk.y & 0xffff), e3 = (uint16_t)(pk.y >> 16);
+#pragma unroll
+        for (int kx = 0; kx < NKX; ++kx) {
+          const int xx = hx - kx;                        // column of this halo pixel in image kx
+          if (xx >= 0 && xx < kGTX) {
+            unsigned char* d = x_s + ((kx * 64 + q * 4) * kXPitch) + (hy * kGTX + xx) * 2;
+            *reinterpret_cast<uint16_t*>(d) = e0;
+            *reinterpret_cast<uint16_t*>(d + kXPitch) = e1;
+            *reinterpret_cast<uint16_t*>(d + 2 * kXPitch) = e2;
+            *reinterpret_cast<uint16_t*>(d + 3 * kXPitch) = e3;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 8 k-steps of 16 pixels (row y, half s): A = gy^T[co][k], B = x^T[kx][ci][row y + ky][k] ---------------------------------
+    const unsigned char* ga = gy_s + (mf * 32 + r) * kGyPitch + h * 16;
+    const unsigned char* xa = x_s + (nf * 32 + r) * kXPitch + h * 16;
+#pragma unroll
+    for (int ks = 0; ks < kGTY * 2; ++ks) {
+      const int y = ks >> 1, s = ks & 1;
+      const uint4 af = *reinterpret_cast<const uint4*>(ga + (y * kGTX + s * 16) * 2);
+#pragma unroll
+      for (int t = 0; t < KS * KS; ++t) {
+        const int ky = t / KS, kx = t - ky * KS;
+        const uint4 bf = *reinterpret_cast<const uint4*>(xa + kx * 64 * kXPitch + ((y + ky) * kGTX + s * 16) * 2);
+        acc[t] = mfma<true>(af, bf, acc[t]);
+      }
+    }
+  }
+  // ---- partial[slab][tap][ci][co]: lane (r = ci, h) holds couts (i&3) + 8 (i>>2) + 4h of its fragment ---------------------------
+  float* pp = a.partial + ((long long)slab * (KS * KS)) * a.cin * a.cout;
+#pragma unroll
+  for (int t = 0; t < KS * KS; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = co0 + mf * 32 + 8 * g + 4 * h, ci = ci0 + nf * 32 + r;
+      *reinterpret_cast<float4*>(pp + ((long long)t * a.cin + ci) * a.cout + co) =
+          make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+    }
+}
+
+}  // namespace fcvsr
+
+static int wgrad_mfma_slabs(int B, int Ho, int Wo, int cin, int cout) {
+  const int tiles = B * ((Ho + 3) / 4) * ((Wo + 31) / 32);
+  int n = 256 / ((cin / 64) * (cout / 64));             // one workgroup per CU
+  if (n > tiles) n = tiles;
+  if (n < 1) n = 1;
+  return n;
+}
+
+extern "C" long long fcvsr_conv2d_wgrad_mfma_scratch_elems(int B, int Ho, int Wo, int cin, int cout, int kh, int kw) {
+  return (long long)wgrad_mfma_slabs(B, Ho, Wo, cin, cout) * kh * kw * cin * cout;
+}
+
+extern "C" int fcvsr_conv2d_wgrad_mfma_eligible(int cin, int cout, int kh, int kw, int stride, int pad) {
+  return (kh == kw && (kh == 1 || kh == 3) && stride == 1 && pad == kh / 2 && cin % 64 == 0 && cout % 64 == 0) ? 1 : 0;
+}
+
+// Same contract as fcvsr_conv2d_wgrad (f32 NHWC x / gy views, f32 (cout,cin,kh,kw) result), products in bf16 on the matrix cores.
+extern "C" int fcvsr_conv2d_wgrad_mfma(const fcvsr_view* x, const fcvsr_view* gy, int B, int H, int W, int kh, int kw, int stride, int pad,
+                                       float* dw, float* scratch, long long scratch_elems, void* stream) {
+  FCVSR_CHECK_ARG(x && gy && dw && scratch, "null argument");
+  FCVSR_CHECK_ARG(x->dtype == FCVSR_F32 && gy->dtype == FCVSR_F32 && x->sc == 1 && gy->sc == 1 && x->ptr && gy->ptr,
+                  "x and gy must be channel-contiguous f32 views");
+  FCVSR_CHECK_ARG(fcvsr_conv2d_wgrad_mfma_eligible(x->c, gy->c, kh, kw, stride, pad), "layer not eligible for the matrix-core weight gradient");
+  FCVSR_CHECK_ARG(x->sx % 4 == 0 && x->sy % 4 == 0 && x->sb % 4 == 0 && gy->sx % 4 == 0 && gy->sy % 4 == 0 && gy->sb % 4 == 0 &&
+                      ((uintptr_t)x->ptr % 16) == 0 && ((uintptr_t)gy->ptr % 16) == 0, "views must be 16-byte aligned");
+  WgradArgs a;
+  a.x = to_view(*x); a.gy = to_view(*gy);
+  a.B = B; a.H = H; a.W = W; a.kh = kh; a.kw = kw; a.stride = 1; a.pad = pad;
+  a.Ho = H; a.Wo = W; a.cin = x->c; a.cout = gy->c;
+  a.npix = (long long)B * H * W;
+  a.n_slabs = wgrad_mfma_slabs(B, H, W, a.cin, a.cout);
+  FCVSR_CHECK_ARG(scratch_elems >= (long long)a.n_slabs * kh * kw * a.cin * a.cout, "scratch too small (fcvsr_conv2d_wgrad_mfma_scratch_elems)");
+  a.slab_pix = 0;
+  a.partial = scratch; a.dw = dw;
+  const int tiles_x = cdiv(W, kGTX), tiles_y = cdiv(H, kGTY);
+  const int total = B * tiles_x * tiles_y;
+  const int per_slab = (total + a.n_slabs - 1) / a.n_slabs;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(a.n_slabs, (a.cin / 64) * (a.cout / 64));
+  if (kh == 3) {
+    const size_t ldsb = 64 * kGyPitch + 3 * 64 * ((kGTY + 2) * kGTX * 2 + 16);
+    static bool attr3 = false;
+    if (!attr3) {
+      hipError_t e = hipFuncSetAttribute((const void*)wgrad_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+      if (e != hipSuccess) { set_error("fcvsr_conv2d_wgrad_mfma: %s", hipGetErrorString(e)); return (int)e; }
+      attr3 = true;
+    }
+    hipLaunchKernelGGL(wgrad_mfma_kernel<3>, grid, dim3(256), ldsb, st, a, tiles_x, tiles_y, per_slab);
+  } else {
+    const size_t ldsb = 64 * kGyPitch + 64 * (kGTY * kGTX * 2 + 16);
+    hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), ldsb, st, a, tiles_x, tiles_y, per_slab);
+  }
+  FCVSR_LAUNCH_CHECK();
+  const long long n = (long long)a.cout * a.cin * kh * kw;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}

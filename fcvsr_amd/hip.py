@@ -71,6 +71,10 @@ SIGNATURES = {
     "fcvsr_conv2d_wgrad_scratch_elems": [C.c_int] * 7,
     "fcvsr_conv2d_wgrad": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                            C.c_longlong, C.c_void_p],
+    "fcvsr_conv2d_wgrad_mfma_eligible": [C.c_int] * 6,
+    "fcvsr_conv2d_wgrad_mfma_scratch_elems": [C.c_int] * 7,
+    "fcvsr_conv2d_wgrad_mfma": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                C.c_longlong, C.c_void_p],
     "fcvsr_abi_version": [],
     "fcvsr_device_count": [],
     "fcvsr_conv2d": [C.POINTER(ConvDesc), _VP],
@@ -107,7 +111,8 @@ SIGNATURES = {
     "fcvsr_bilinear_up4": [_PV, _I, _I, _I, _PV, _VP],
     "fcvsr_tail_fused": [_PV, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _PV, _VP],
 }
-_RESTYPES = {"fcvsr_last_error": C.c_char_p, "fcvsr_last_conv_kernel": C.c_char_p, "fcvsr_conv2d_wgrad_scratch_elems": C.c_longlong}
+_RESTYPES = {"fcvsr_last_error": C.c_char_p, "fcvsr_last_conv_kernel": C.c_char_p, "fcvsr_conv2d_wgrad_scratch_elems": C.c_longlong,
+             "fcvsr_conv2d_wgrad_mfma_scratch_elems": C.c_longlong}
 
 
 def lib() -> C.CDLL:

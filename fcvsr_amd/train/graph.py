@@ -71,23 +71,15 @@ def _corr_lookup(x1f: Tensor, x2f: Tensor, radius: int = 4) -> Tensor:
     n = 2 * radius + 1
     dev = x1f.device
     img = ((x1f * x2f).contiguous().reshape(B, C * H * Wf) / math.sqrt(float(C))).reshape(B, H * Wf, C // 2, 2)
-    ys = torch.arange(H, device=dev).view(H, 1).expand(H, Wf)
-    xs = torch.arange(Wf, device=dev).view(1, Wf).expand(H, Wf)
-    pix = ys * Wf + xs
-    planes = []
-    zero = torch.zeros(B, H, Wf, dtype=x1f.dtype, device=dev)
-    for i in range(n):
-        col = xs + (i - radius)
-        cok = (col >= 0) & (col <= 1)
-        for j in range(n):
-            row = ys + (j - radius)
-            ok = cok & (row >= 0) & (row <= C // 2 - 1)
-            if not bool(ok.any()):
-                planes.append(zero)
-                continue
-            v = img[:, pix, row.clamp(0, C // 2 - 1), col.clamp(0, 1)]
-            planes.append(v * ok.to(v.dtype))
-    return torch.stack(planes, 1)
+    ys = torch.arange(H, device=dev).view(1, 1, H, 1)
+    xs = torch.arange(Wf, device=dev).view(1, 1, 1, Wf)
+    pix = (ys * Wf + xs).expand(n, n, H, Wf)
+    d = torch.arange(n, device=dev) - radius
+    col = (xs + d.view(n, 1, 1, 1)).expand(n, n, H, Wf)             # output channel c = i * n + j: i shifts the column ...
+    row = (ys + d.view(1, n, 1, 1)).expand(n, n, H, Wf)             # ... j the row (meshgrid(dy, dx) added to (x, y), :1303-1309)
+    ok = (col >= 0) & (col <= 1) & (row >= 0) & (row <= C // 2 - 1)
+    v = img[:, pix, row.clamp(0, C // 2 - 1), col.clamp(0, 1)]      # ONE gather for all 81 planes: (B, n, n, H, Wf)
+    return (v * ok.to(v.dtype)).reshape(B, n * n, H, Wf)
 
 
 def _warp(x: Tensor, off: Tensor) -> Tensor:

@@ -7,7 +7,8 @@ Tensors are (B,C,H,W) in torch's channels_last memory format, i.e. NHWC in memor
 
 precision "f32": exact-f32 direct kernels in all directions (the mode the gradient goldens are checked in).
 precision "bf16"/"f16": forward and input gradient on the matrix cores (fcvsr_conv2d_mfma, f32 accumulate) when the layer is
-eligible (1x1 / 3x3, channel counts the MFMA path takes), weight gradient exact f32 from the same activations.
+eligible (1x1 / 3x3, channel counts the MFMA path takes); weight gradient with bf16 products on the matrix cores for the
+3x3 / 1x1 layers with multiples of 64 channels (fcvsr_conv2d_wgrad_mfma), exact f32 for the rest.
 """
 from __future__ import annotations
 
@@ -72,13 +73,16 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             L = hip.lib()
             Ho, Wo = gyv.shape[1], gyv.shape[2]
-            n = L.fcvsr_conv2d_wgrad_scratch_elems(B, Ho, Wo, cin, cout, k, k)
+            # 16-bit modes: products on the matrix cores for the 3x3 / 1x1 layers with multiples of 64 channels; exact f32 otherwise
+            mm = precision in _MMA and L.fcvsr_conv2d_wgrad_mfma_eligible(cin, cout, k, k, stride, k // 2)
+            n = (L.fcvsr_conv2d_wgrad_mfma_scratch_elems if mm else L.fcvsr_conv2d_wgrad_scratch_elems)(B, Ho, Wo, cin, cout, k, k)
             scratch = torch.empty(n, dtype=torch.float32, device=xv.device)
             gw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=xv.device)
             import ctypes as C
             xd, gd = hip.view(xv), hip.view(gyv)
-            hip.check(L.fcvsr_conv2d_wgrad(C.addressof(xd), C.addressof(gd), B, H, W, k, k, stride, k // 2, gw.data_ptr(),
-                                           scratch.data_ptr(), n, hip.stream_ptr()), "fcvsr_conv2d_wgrad")
+            fn = L.fcvsr_conv2d_wgrad_mfma if mm else L.fcvsr_conv2d_wgrad
+            hip.check(fn(C.addressof(xd), C.addressof(gd), B, H, W, k, k, stride, k // 2, gw.data_ptr(), scratch.data_ptr(), n,
+                         hip.stream_ptr()), "fcvsr_conv2d_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gyv.sum(dim=(0, 1, 2))
         return gx, gw, gb, None, None

@@ -106,6 +106,12 @@ int fcvsr_conv2d_f32mfma(const fcvsr_conv_desc* d, void* stream);
 long long fcvsr_conv2d_wgrad_scratch_elems(int B, int Ho, int Wo, int cin, int cout, int kh, int kw);
 int fcvsr_conv2d_wgrad(const fcvsr_view* x, const fcvsr_view* gy, int B, int H, int W, int kh, int kw, int stride, int pad,
                        float* dw, float* scratch, long long scratch_elems, void* stream);
+/* The same weight gradient with bf16 products on the matrix cores (f32 accumulation, deterministic slab order): 3x3 / 1x1,
+ * stride 1, cin and cout multiples of 64 (fcvsr_conv2d_wgrad_mfma_eligible); same arguments and result layout. */
+int fcvsr_conv2d_wgrad_mfma_eligible(int cin, int cout, int kh, int kw, int stride, int pad);
+long long fcvsr_conv2d_wgrad_mfma_scratch_elems(int B, int Ho, int Wo, int cin, int cout, int kh, int kw);
+int fcvsr_conv2d_wgrad_mfma(const fcvsr_view* x, const fcvsr_view* gy, int B, int H, int W, int kh, int kw, int stride, int pad,
+                            float* dw, float* scratch, long long scratch_elems, void* stream);
 /* Diagnostic (FCVSR_RES_STAMPS=1 in the environment): copies the in-kernel cycle stamps the last resident-weight convolution
  * launch recorded for one workgroup, [wave 8][phase 64][slot 8] uint64, to host memory.  Not part of the data path. */
 int fcvsr_debug_res_stamps(void* host_out, size_t bytes);

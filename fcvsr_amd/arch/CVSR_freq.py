@@ -207,6 +207,9 @@ class _GShiftBase(nn.Module):
         self.fast_feat = os.environ.get("FCVSR_FAST_FEAT", "1") == "1"
         # 16-bit modes, n_features == 64: convcrt and (away from the CorrBlock strip) convcorr as one launch each
         self.fuse_freq_head = os.environ.get("FCVSR_FUSE_FREQ_HEAD", "1") == "1"
+        # 16-bit modes, 16-bit trunk: ContextBlock partials from the stored r in their own launch (the conv then runs on the
+        # resident-weight kernel) instead of from the lean kernel's epilogue
+        self.gc_separate = os.environ.get("FCVSR_GC_SEPARATE", "1") == "1"
         # capture the launch sequence of a forward in a hipGraph (per input shape) and replay it
         self.use_graph = os.environ.get("FCVSR_GRAPH", "0") == "1"
         # captured graphs kept per (shape, precision, streams, flags): least-recently-used entries beyond this are freed

@@ -1382,16 +1382,28 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
     if (res_mode == 0 || (res_mode == 2 && rtiles * (cin == 64 ? d0.cout / 64 : d0.cout / 32) < res_min)) res = false;
   }
   if (res) {
-    static void* zeros = nullptr;                    // per process; allocated outside any stream capture by Engine warm-up
-    if (!zeros) {
-      hipError_t ez = hipMalloc(&zeros, 256);
-      if (ez == hipSuccess) ez = hipMemset(zeros, 0, 256);
+    // 256 zero bytes per DEVICE (the source of halo pixels outside the image), created on first use.  hipMalloc / hipMemset are
+    // not capturable: the engine runs every configuration eagerly before it captures a hipGraph, so this never happens inside
+    // a capture; a capture that does reach it fails loudly here rather than reading another device's page.
+    static void* zeros_dev[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { set_error("fcvsr_conv2d_mfma: bad device index"); return FCVSR_E_ARG; }
+    if (!zeros_dev[dev]) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        set_error("fcvsr_conv2d_mfma: first use on this device inside a stream capture (run the layer once eagerly first)");
+        return FCVSR_E_ARG;
+      }
+      void* z = nullptr;
+      hipError_t ez = hipMalloc(&z, 256);
+      if (ez == hipSuccess) ez = hipMemset(z, 0, 256);
       if (ez != hipSuccess) {
-        zeros = nullptr;
         set_error("fcvsr_conv2d_mfma: zero page allocation failed: %s", hipGetErrorString(ez));
         return (int)ez;
       }
+      zeros_dev[dev] = z;
     }
+    void* zeros = zeros_dev[dev];
     ResArgs wa;
     wa.n_groups = n_groups;
     int wtiles = 0;

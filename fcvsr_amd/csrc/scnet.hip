@@ -669,3 +669,104 @@ extern "C" int fcvsr_xscale_levels(const fcvsr_xscale_level* lv, int n_levels, i
   FCVSR_LAUNCH_CHECK();
   return 0;
 }
+
+// =====================================================================================================================
+// ContextBlock softmax-pool partials from a STORED 16-bit r (all pyramid levels in one launch).  The lean 3x3 kernel can emit
+// these from its epilogue (fcvsr_conv_desc.gc_wmask), but that epilogue costs it a third of its speed (185 vs 127 us for the
+// 64 -> 64 layer); with the resident-weight kernel taking the layer (102 us) it is cheaper to re-read r once (203 MB per
+// launch set, mostly from L2 / Infinity Cache right behind the producer) and compute the partials here.
+// One workgroup = one 4 x 32 pixel tile = the partition (and [C+2] record layout) of the fused epilogue, so
+// fcvsr_gc_finish_levels consumes either.  Two passes over registers: tile maximum of the logits first, then exp / sums, all in
+// fixed order (bit-reproducible).
+#include "mfma_util.h"
+namespace fcvsr {
+
+struct GcPartLv { const uint16_t* r; float* partial; int B, H, W, tiles_x, tiles_y, tile_begin; };
+struct GcPartArgs { GcPartLv lv[3]; int n_levels; const float* wmask; };
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void gc_partial16_levels_kernel(GcPartArgs a) {
+  __shared__ float red_m[4];
+  __shared__ float red_s[4];
+  __shared__ __align__(16) float red_a[4][64];
+  int t = blockIdx.x, li = 0;
+  if (a.n_levels > 1 && t >= a.lv[1].tile_begin) li = 1;
+  if (a.n_levels > 2 && t >= a.lv[2].tile_begin) li = 2;
+  const GcPartLv L = a.lv[li];
+  t -= L.tile_begin;
+  const int per_img = L.tiles_x * L.tiles_y;
+  const int b = t / per_img, t2 = t - b * per_img;
+  const int ty0 = (t2 / L.tiles_x) * 4, tx0 = (t2 % L.tiles_x) * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int oct = tid & 7, ps = tid >> 3;                // 8 channels per lane, 32 pixels per pass, 4 passes (= 4 tile rows)
+  const float4 w0 = *reinterpret_cast<const float4*>(a.wmask + oct * 8), w1 = *reinterpret_cast<const float4*>(a.wmask + oct * 8 + 4);
+  float v[4][8], logit[4];
+  bool ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int py = ty0 + j, px = tx0 + ps;
+    ok[j] = py < L.H && px < L.W;
+    uint4 raw = make_uint4(0, 0, 0, 0);
+    if (ok[j]) raw = *reinterpret_cast<const uint4*>(L.r + (((long long)b * L.H + py) * L.W + px) * 64 + oct * 8);
+    cvt16x4_to_f32<BF16>(make_uint2(raw.x, raw.y), v[j]);
+    cvt16x4_to_f32<BF16>(make_uint2(raw.z, raw.w), v[j] + 4);
+    float p = v[j][0] * w0.x + v[j][1] * w0.y + v[j][2] * w0.z + v[j][3] * w0.w + v[j][4] * w1.x + v[j][5] * w1.y + v[j][6] * w1.z + v[j][7] * w1.w;
+    p += __shfl_xor(p, 1); p += __shfl_xor(p, 2); p += __shfl_xor(p, 4);      // the 8 lanes of a pixel
+    logit[j] = ok[j] ? p : -INFINITY;
+  }
+  float m = fmaxf(fmaxf(logit[0], logit[1]), fmaxf(logit[2], logit[3]));
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (lane == 0) red_m[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));                // the tile has at least one live pixel
+  float s = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float e = ok[j] ? expf(logit[j] - m) : 0.f;
+    s += e;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = fmaf(e, v[j][c], acc[c]);
+  }
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {                      // the 8 pixel slots of a wave (same channel octet)
+    s += __shfl_xor(s, o);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] += __shfl_xor(acc[c], o);
+  }
+  if (lane < 8) {
+    *reinterpret_cast<float4*>(&red_a[wave][lane * 8]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(&red_a[wave][lane * 8 + 4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    if (lane == 0) red_s[wave] = s;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float* pp = L.partial + ((long long)b * per_img + t2) * 66;
+    pp[tid] = (red_a[0][tid] + red_a[1][tid]) + (red_a[2][tid] + red_a[3][tid]);
+    if (tid == 0) { pp[64] = m; pp[65] = (red_s[0] + red_s[1]) + (red_s[2] + red_s[3]); }
+  }
+}
+
+}  // namespace fcvsr
+
+extern "C" int fcvsr_gc_partial_levels(const fcvsr_gc_partial_level* lv, int n_levels, int r_dtype, const float* wmask, int C, void* stream) {
+  FCVSR_CHECK_ARG(lv && n_levels >= 1 && n_levels <= 3 && wmask && C == 64, "1..3 levels, 64 channels");
+  FCVSR_CHECK_ARG(r_dtype == FCVSR_BF16 || r_dtype == FCVSR_F16, "r must be stored in 16 bit");
+  FCVSR_CHECK_ARG(((uintptr_t)wmask % 16) == 0, "wmask must be 16-byte aligned");
+  fcvsr::GcPartArgs a;
+  a.n_levels = n_levels; a.wmask = wmask;
+  int tiles = 0;
+  for (int l = 0; l < 3; ++l) {
+    const fcvsr_gc_partial_level& s = lv[l < n_levels ? l : 0];
+    FCVSR_CHECK_ARG(s.r && s.partial && s.B > 0 && s.H > 0 && s.W > 0 && ((uintptr_t)s.r % 16) == 0, "bad level");
+    fcvsr::GcPartLv& L = a.lv[l];
+    L.r = (const uint16_t*)s.r; L.partial = s.partial; L.B = s.B; L.H = s.H; L.W = s.W;
+    L.tiles_x = fcvsr::cdiv(s.W, 32); L.tiles_y = fcvsr::cdiv(s.H, 4);
+    L.tile_begin = tiles;
+    if (l < n_levels) tiles += s.B * L.tiles_x * L.tiles_y;
+  }
+  if (r_dtype == FCVSR_BF16) hipLaunchKernelGGL(fcvsr::gc_partial16_levels_kernel<true>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(fcvsr::gc_partial16_levels_kernel<false>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}

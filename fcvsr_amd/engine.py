@@ -548,8 +548,19 @@ class Engine:
         w1g, w2g = par[pre + ".RCB.gcnet.channel_add_conv.0.weight"], par[pre + ".RCB.gcnet.channel_add_conv.2.weight"]
         nparts = [((x.shape[1] + 3) // 4) * ((x.shape[2] + 31) // 32) for x in xs]
         parts = [self._new(x.device, x.shape[0], npt, n + 2) for x, npt in zip(xs, nparts)]
-        fused_gc = self._convg(pre + ".RCB.body.2", [dict(srcs=[a], dst=t, gc_partial=pt) for a, t, pt in zip(r1, rr, parts)],
-                               gc_wmask=wmask if self.precision != "f32" else None)
+        if r16 and n == 64 and getattr(m, "gc_separate", True):
+            # r is stored in 16 bit anyway: run the layer without the ContextBlock epilogue (it then goes to the resident-weight
+            # kernel: 102 vs 185 us) and compute the softmax-pool partials from the stored r in one launch for all levels
+            self._convg(pre + ".RCB.body.2", [dict(srcs=[a], dst=t) for a, t in zip(r1, rr)])
+            pl = (hip.GcPartialLevel * 3)()
+            for l, x in enumerate(xs):
+                pl[l].r, pl[l].partial = rr[l].data_ptr(), parts[l].data_ptr()
+                pl[l].B, pl[l].H, pl[l].W = x.shape[0], x.shape[1], x.shape[2]
+            check(L.fcvsr_gc_partial_levels(pl, 3, self._code(rr[0].dtype), wmask.data_ptr(), n, st), "fcvsr_gc_partial_levels")
+            fused_gc = True
+        else:
+            fused_gc = self._convg(pre + ".RCB.body.2", [dict(srcs=[a], dst=t, gc_partial=pt) for a, t, pt in zip(r1, rr, parts)],
+                                   gc_wmask=wmask if self.precision != "f32" else None)
         if fused_gc and getattr(m, "pool_first", True):
             return self._block_rcb_tail_levels(pre, xs, t2, rr, parts, nparts, w1g, w2g, tdt)
         R = []
@@ -667,7 +678,7 @@ class Engine:
             self._refresh(dev)
             ns = max(1, min(int(getattr(m, "streams", 1)), B))
             flags = tuple(bool(getattr(m, f, True)) for f in ("trunk16", "fold_f1", "fuse_tail", "pool_first", "fuse_freq_mlp",
-                                                              "fuse_freq_head", "fast_feat", "fuse_rcb_tail"))
+                                                              "fuse_freq_head", "fast_feat", "fuse_rcb_tail", "gc_separate"))
             cfg = (tuple(x.shape[1:]), self.precision, str(dev), self._pack_epoch, flags)
             if ns > 1 and cfg not in self._warm:
                 # First pass of a configuration: re-packed weights, band masks and per-kernel attributes are created lazily

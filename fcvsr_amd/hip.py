@@ -29,6 +29,10 @@ class GcFinishLevel(C.Structure):
     _fields_ = [("partial", C.c_void_p), ("add", C.c_void_p), ("nparts", C.c_int32)]
 
 
+class GcPartialLevel(C.Structure):
+    _fields_ = [("r", C.c_void_p), ("partial", C.c_void_p), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32)]
+
+
 class GcApplyLevel(C.Structure):
     _fields_ = [("r", C.c_void_p), ("add", C.c_void_p), ("z", C.c_void_p), ("out", C.c_void_p), ("pool", C.c_void_p),
                 ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32)]
@@ -105,6 +109,7 @@ SIGNATURES = {
     "fcvsr_gc_apply": [_VP, _VP, _VP, _VP, _I, _F, _I, _I, _I, _I, _VP],
     "fcvsr_xscale": [_VP, _VP, _F, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP],
     "fcvsr_gc_finish_levels": [C.POINTER(GcFinishLevel), _I, _VP, _VP, _I, _I, _VP],
+    "fcvsr_gc_partial_levels": [C.POINTER(GcPartialLevel), _I, _I, _VP, _I, _VP],
     "fcvsr_gc_apply_levels": [C.POINTER(GcApplyLevel), _I, _I, _I, _F, _I, _VP],
     "fcvsr_xscale_levels": [C.POINTER(XscaleLevel), _I, _I, _I, _VP],
     "fcvsr_pixel_shuffle": [_VP, _VP, _I, _I, _I, _I, _VP],

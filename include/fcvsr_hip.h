@@ -275,6 +275,17 @@ int fcvsr_xscale_levels(const fcvsr_xscale_level* lv, int n_levels, int io_dtype
 
 /* ---- tail ------------------------------------------------------------------------------------------------------ */
 /* nn.PixelShuffle(2) of a dense NHWC tensor (B,H,W,C) -> (B,2H,2W,C/4) (:2634-2635) */
+/* ContextBlock softmax-pool partials (:657-701) from a STORED 16-bit r, all pyramid levels in one launch: one [C+2] record per
+ * 4 x 32 pixel tile (sum_p exp(l_p - m) r_p[c], m = max l_p, sum exp; l_p = <r_p, wmask>), the layout fcvsr_conv2d_mfma's fused
+ * epilogue writes - fcvsr_gc_finish_levels consumes either.  r: dense (B,H,W,64) in r_dtype (BF16 / F16);
+ * partial: [B][ceil(H/4)*ceil(W/32)][66] floats. */
+typedef struct {
+  const void* r;
+  float*      partial;
+  int32_t     B, H, W;
+} fcvsr_gc_partial_level;
+int fcvsr_gc_partial_levels(const fcvsr_gc_partial_level* lv, int n_levels, int r_dtype, const float* wmask, int C, void* stream);
+
 int fcvsr_pixel_shuffle(const float* src, float* dst, int B, int H, int W, int C, void* stream);
 /* F.interpolate(scale_factor=4, bilinear, align_corners=False) (:2644): src view (B,H,W,c) -> dst view (B,4H,4W,c) */
 int fcvsr_bilinear_up4(const fcvsr_view* src, int B, int H, int W, const fcvsr_view* dst, void* stream);

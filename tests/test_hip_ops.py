@@ -555,3 +555,37 @@ def test_conv_f32_matrix_core_pixel_shuffle_and_skinny_outputs():
         torch.cuda.synchronize()
         assert float((out_m - out_d).abs().max()) <= 2e-6 * max(1.0, float(out_d.abs().max()))
         assert float((out_d - base).abs().max()) > 0.1
+
+
+def test_gc_partials_from_stored_r_match_the_reference_formula():
+    """fcvsr_gc_partial_levels: per 4 x 32 tile, (sum_p exp(l_p - m) r_p, m, sum exp) of a stored bf16 r over three levels with
+    partial tiles; combined by fcvsr_gc_finish_levels they must give the ContextBlock vector of the f64 formula (:657-701)."""
+    from fcvsr_amd import hip
+    L = hip.lib()
+    g0 = torch.Generator().manual_seed(3)
+    B, n = 2, 64
+    shapes = [(22, 70), (11, 35), (6, 18)]
+    wmask = (torch.randn(n, generator=g0) * 0.3).cuda()
+    w1 = (torch.randn(n, n, generator=g0) / 8).cuda()
+    w2 = (torch.randn(n, n, generator=g0) / 8).cuda()
+    rs = [torch.randn(B, H, W, n, generator=g0).cuda().to(torch.bfloat16) for H, W in shapes]
+    nparts = [((H + 3) // 4) * ((W + 31) // 32) for H, W in shapes]
+    parts = [torch.full((B, npt, n + 2), float("nan"), device="cuda") for npt in nparts]
+    adds = [torch.empty(B, n, device="cuda") for _ in shapes]
+    pl = (hip.GcPartialLevel * 3)()
+    fl = (hip.GcFinishLevel * 3)()
+    for l, (H, W) in enumerate(shapes):
+        pl[l].r, pl[l].partial, pl[l].B, pl[l].H, pl[l].W = rs[l].data_ptr(), parts[l].data_ptr(), B, H, W
+        fl[l].partial, fl[l].add, fl[l].nparts = parts[l].data_ptr(), adds[l].data_ptr(), nparts[l]
+    hip.check(L.fcvsr_gc_partial_levels(pl, 3, hip.BF16, wmask.data_ptr(), n, hip.stream_ptr()), "gc_partial_levels")
+    hip.check(L.fcvsr_gc_finish_levels(fl, 3, w1.data_ptr(), w2.data_ptr(), B, n, hip.stream_ptr()), "gc_finish_levels")
+    torch.cuda.synchronize()
+    for l, r in enumerate(rs):
+        assert not torch.isnan(parts[l]).any()
+        rd = r.double().reshape(B, -1, n)
+        logits = rd @ wmask.double()
+        ctx = (torch.softmax(logits, 1).unsqueeze(-1) * rd).sum(1)
+        t = ctx @ w1.double().t()
+        t = torch.where(t >= 0, t, 0.2 * t)
+        ref = t @ w2.double().t()
+        assert float((adds[l].double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))

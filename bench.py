@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the sub-records (batch-1 latency, full model, f32 mode)")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step sub-record (BASELINE config 3)")
     ap.add_argument("--train-precision", choices=["f32", "bf16", "f16"], default="bf16")
+    ap.add_argument("--train-graph", type=int, default=1, help="1: replay forward + backward of the training step from a hipGraph")
     ap.add_argument("--stub", action="store_true",
                     help="launch-plumbing rehearsal without a GPU: the step is a no-op on CPU tensors and the line says so "
                          "(metric 'stub'); used by tests/test_dist_cpu.py with --backend gloo")
@@ -332,7 +333,7 @@ def main():
             g = torch.Generator().manual_seed(300 + rank)                       # different data per rank, same weights
             tx = torch.rand(4, 7, 1, 128, 128, generator=g).to(dev)
             th = torch.rand(4, 1, 512, 512, generator=g).to(dev)
-            step = TrainStep(tm, lr=1e-4, weight_decay=1e-5)
+            step = TrainStep(tm, lr=1e-4, weight_decay=1e-5, use_graph=bool(args.train_graph))
             step(tx, th)                                                         # warm-up (allocations, weight packing)
             torch.cuda.synchronize()
             if world > 1:
@@ -350,7 +351,7 @@ def main():
                                  "flat f32 gradient all-reduce (SUM)", "world": world, "global_batch": 4 * world,
                      "conv_precision": args.train_precision + (" forward / input-gradient / weight-gradient on MFMA (f32 accumulate)" if args.train_precision != "f32" else " (exact)"),
                      "ms_per_step": round(sec * 1e3, 2), "clips_per_s": round(4 * world / sec, 2),
-                     "allreduce_bytes": int(step.allreduce.numel * 4), "finite_loss": bool(np.isfinite(lv))}
+                     "allreduce_bytes": int(step.allreduce.numel * 4), "finite_loss": bool(np.isfinite(lv)), "hipgraph": bool(args.train_graph)}
             log(f"train sub-record: {train}")
             del tm, step, tx, th
         except Exception as e:                                                   # a sub-record must never cost the headline line

@@ -143,9 +143,20 @@ def _mgaa(c: _Ctx, key: str, x: Tensor, A: int) -> Tensor:
     return c.conv(key + ".conv3", torch.cat(al, 1)) + x2
 
 
+_MASKS_DEV: Dict[tuple, Tensor] = {}
+
+
+def _dev_masks(Q: int, H: int, W: int, dev) -> Tensor:
+    """Band masks on the device, cached (no host-to-device copy inside a forward: the step can be captured in a hipGraph)."""
+    key = (Q, H, W, str(dev))
+    if key not in _MASKS_DEV:
+        _MASKS_DEV[key] = band_masks_half(Q, H, W).to(dev)
+    return _MASKS_DEV[key]
+
+
 def _mffr(c: _Ctx, key: str, x: Tensor, Q: int) -> Tensor:
     B, C, H, W = x.shape
-    M = band_masks_half(Q, H, W).to(x.device)
+    M = _dev_masks(Q, H, W, x.device)
     X = torch.fft.rfft2(x.contiguous())
     freq = [torch.fft.irfft2(X * M[n], s=(H, W)) for n in range(Q)][::-1]
     s_f = torch.zeros_like(x)

@@ -80,8 +80,13 @@ class TrainStep:
 
     def __init__(self, model: torch.nn.Module, *, lr: float = 1e-4, weight_decay: float = 1e-5,
                  loss_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor] = charbonnier_loss, reduce_op: str = "sum",
-                 optimizer: Optional[torch.optim.Optimizer] = None, group=None):
+                 optimizer: Optional[torch.optim.Optimizer] = None, group=None, use_graph: bool = False):
+        """use_graph: capture forward + loss + backward of the first batch shape in a hipGraph and replay it (the step is ~4 k
+        small launches; replaying removes their host cost).  Gradients then live in static buffers; the all-reduce and the
+        optimizer step stay eager.  Batches must keep the captured shape (a different shape is captured anew)."""
         self.model = model
+        self.use_graph = use_graph
+        self._graphs = {}
         named = trainable_parameters(model)
         self.names = [n for n, _ in named]
         params = [p for _, p in named]
@@ -92,13 +97,47 @@ class TrainStep:
 
     def __call__(self, lr_frames: torch.Tensor, hr: torch.Tensor) -> float:
         """lr_frames: (b, 7, C, h, w), hr: (b, C, 4h, 4w) - this rank's share of the batch."""
-        self.optimizer.zero_grad(set_to_none=True)
-        sr = self.model(lr_frames)
-        loss = self.loss_fn(sr, hr)
-        loss.backward()
+        if self.use_graph and lr_frames.is_cuda:
+            loss = self._graphed(lr_frames, hr)
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+            sr = self.model(lr_frames)
+            loss = self.loss_fn(sr, hr)
+            loss.backward()
         self.allreduce()
         self.optimizer.step()
         return float(loss.detach())
+
+    def _graphed(self, lr_frames: torch.Tensor, hr: torch.Tensor) -> torch.Tensor:
+        key = (tuple(lr_frames.shape), tuple(hr.shape), str(lr_frames.device))
+        ent = self._graphs.get(key)
+        if ent is None:
+            sx, sh = lr_frames.clone(), hr.clone()
+            params = self.allreduce.params
+            # warm-up on a side stream (allocations, weight packing, per-kernel attributes, per-device zero page), as
+            # torch.cuda.graphs requires; leaves .grad tensors allocated so the capture accumulates into static buffers
+            side = torch.cuda.Stream(lr_frames.device)
+            side.wait_stream(torch.cuda.current_stream(lr_frames.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.optimizer.zero_grad(set_to_none=True)
+                    self.loss_fn(self.model(sx), sh).backward()
+            torch.cuda.current_stream(lr_frames.device).wait_stream(side)
+            for p in params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for p in params:
+                    p.grad.zero_()
+                loss = self.loss_fn(self.model(sx), sh)
+                loss.backward()
+            ent = self._graphs[key] = (graph, sx, sh, loss)
+        graph, sx, sh, loss = ent
+        sx.copy_(lr_frames)
+        sh.copy_(hr)
+        graph.replay()
+        return loss
 
 
 # ---- data transforms of the reference loader (CVSR_train/opt/data_LD_LR.py:248-344), on {lr_imgs (f,h,w), hr_imgs (f',4h,4w)} ----

@@ -1359,7 +1359,11 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   // LDS-resident-weight persistent kernel (conv_res.hip): one dense 16-bit source of 64 or 128 channels, cout a multiple of
   // 64, channel-contiguous 16-byte-aligned destination and residuals, no ContextBlock fusion.  It pays once every workgroup
   // amortises its 72 KiB weight copy over a few 8 x 32 tiles; small launches stay on the lean kernel.
-  bool res = lean && a.src16 && conv3_res_supports(cin, d0.cout) && d0.gc_wmask == nullptr && d0.cout == d0.cout / 64 * 64;
+  // Pixel-shuffled layers (the 3x3 up-convs of the full / RGB models, 64 -> 256) qualify too: with sub-pixel-major rows a
+  // 64-cout block is one sub-pixel, so PixelShuffle is only a different destination pixel (no residuals, 16-bit destination).
+  const bool res_ps = a.ps && dst_native && d0.kh == 3 && d0.stride == 1 && mw == 1 && !wd && d0.n_src == 1 && !a.planar && cin == 64 &&
+                      d0.cout % 256 == 0 && d0.n_res == 0 && a.dst16 && a.src16 && d0.gc_wmask == nullptr;
+  bool res = (lean || res_ps) && a.src16 && conv3_res_supports(cin, d0.cout) && d0.gc_wmask == nullptr && d0.cout == d0.cout / 64 * 64;
   int rtiles = 0;
   for (int g = 0; g < n_groups && res; ++g) {
     const fcvsr_conv_desc& d = descs[g];
@@ -1372,6 +1376,8 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
             ((uintptr_t)d.res[q].ptr % 16) == 0;
     }
     rtiles += conv3_res_tiles(d.B, d.H, d.W);
+    if (res_ps) res = res && d.dst.c == d0.cout / 4 && (long long)d.B * d.dst.sb < (1ll << 29) && (long long)d.B * d.src[0].sb < (1ll << 29) &&
+                      d.src[0].sc == 1 && ((uintptr_t)d.src[0].ptr % 16) == 0;
   }
   {
     // FCVSR_MFMA_RES: 0 never, 1 always (when eligible), unset: by size (FCVSR_MFMA_RES_MIN workgroup-tiles)
@@ -1420,7 +1426,7 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
     wa.total_tiles = wtiles;
     wa.cin = cin; wa.cout = d0.cout; wa.cout_pad = d0.cout_pad; wa.cin_pad = a.cin_pad;
     wa.w = a.w; wa.bias = a.bias; wa.act = a.act; wa.slope = a.slope; wa.slope_ptr = a.slope_ptr;
-    wa.rs[0] = a.rs[0]; wa.rs[1] = a.rs[1]; wa.n_res = a.n_res; wa.res16 = a.res16; wa.zeros = zeros;
+    wa.rs[0] = a.rs[0]; wa.rs[1] = a.rs[1]; wa.n_res = a.n_res; wa.res16 = a.res16; wa.ps = a.ps; wa.zeros = zeros;
     { const char* wd_ = getenv("FCVSR_RES_DBG"); wa.dbg = wd_ ? atoi(wd_) : 0; }
     wa.stamps = nullptr;
     {

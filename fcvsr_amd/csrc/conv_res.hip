@@ -47,7 +47,7 @@ enum {
 };
 
 struct ResK {                                        // kernel arguments
-  int n_groups, total_tiles, cout, cout_pad, cin_pad, act, n_res, res16, dbg;
+  int n_groups, total_tiles, cout, cout_pad, cin_pad, act, n_res, res16, dbg, ps;
   float slope, rs[2];
   const float* slope_ptr;
   const uint16_t* w;
@@ -320,7 +320,11 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResK a) {
           const bool ok = (py < GH) && (px < GW) && !(a.dbg & 4);
           // lanes outside the image read the residuals of the image's first pixel (always a valid address) and store nothing
           const int pyc = ok ? py : 0, pxc = ok ? px : 0;
-          const unsigned dpix = (unsigned)(t.b * T[kTDstSb] + pyc * T[kTDstSy] + pxc * T[kTDstSx] + n0 + 8 * h);   // elements
+          // PixelShuffle(2): rows are packed sub-pixel-major, so this workgroup's 64 couts are 64 consecutive channels of ONE
+          // sub-pixel (i, j): the same store at pixel (2y + i, 2x + j), channel n0 % (cout/4)
+          const int cq4 = a.cout >> 2, sp = a.ps ? n0 / cq4 : 0, nch = a.ps ? n0 - sp * cq4 : n0;
+          const int dyy = a.ps ? 2 * pyc + (sp >> 1) : pyc, dxx = a.ps ? 2 * pxc + (sp & 1) : pxc;
+          const unsigned dpix = (unsigned)(t.b * T[kTDstSb] + dyy * T[kTDstSy] + dxx * T[kTDstSx] + nch + 8 * h);   // elements
           const unsigned r0pix = (unsigned)(t.b * T[kTR0Sb] + pyc * T[kTR0Sy] + pxc * T[kTR0Sx] + n0 + 8 * h);
           const unsigned r1pix = (unsigned)(t.b * T[kTR1Sb] + pyc * T[kTR1Sy] + pxc * T[kTR1Sx] + n0 + 8 * h);
           if (FAST) {
@@ -455,7 +459,7 @@ static hipError_t launch_res(const ResArgs& a, hipStream_t st) {
   if (grid > need) grid = need;
   ResK k;
   k.n_groups = a.n_groups; k.total_tiles = a.total_tiles; k.cout = a.cout; k.cout_pad = a.cout_pad; k.cin_pad = a.cin_pad;
-  k.act = a.act; k.n_res = a.n_res; k.res16 = a.res16; k.dbg = a.dbg; k.slope = a.slope; k.rs[0] = a.rs[0]; k.rs[1] = a.rs[1];
+  k.act = a.act; k.n_res = a.n_res; k.res16 = a.res16; k.dbg = a.dbg; k.ps = a.ps; k.slope = a.slope; k.rs[0] = a.rs[0]; k.rs[1] = a.rs[1];
   k.slope_ptr = a.slope_ptr; k.w = a.w; k.bias = a.bias; k.zeros = a.zeros; k.stamps = a.stamps;
   for (int g = 0; g < 3; ++g) {
     const ResGroup& G = a.g[g < a.n_groups ? g : 0];

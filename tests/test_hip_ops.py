@@ -589,3 +589,28 @@ def test_gc_partials_from_stored_r_match_the_reference_formula():
         t = torch.where(t >= 0, t, 0.2 * t)
         ref = t @ w2.double().t()
         assert float((adds[l].double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_conv_resident_weights_pixel_shuffle_matches_generic(monkeypatch):
+    """3x3 64 -> 256 with PReLU and PixelShuffle(2) (the up-convs of the full / RGB models) on the resident-weight kernel - a
+    64-cout block is one sub-pixel - against the generic MFMA kernel's pixel-shuffle epilogue, bit for bit."""
+    from fcvsr_amd import hip
+    dt = torch.bfloat16
+    g0 = torch.Generator().manual_seed(12)
+    w = torch.randn(256, 64, 3, 3, generator=g0) / 24.0
+    bias = torch.randn(256, generator=g0)
+    wp = hip.pack_conv_weight_mfma(w.cuda(), dt, ps=True)
+    bp = bias[hip.ps_order(256)].contiguous().cuda()
+    slope_t = torch.tensor([0.25]).cuda()
+    x = torch.randn(3, 37, 70, 64, generator=g0).cuda().to(dt)
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FCVSR_MFMA_RES", mode)
+        y = torch.full((3, 74, 140, 64), float("nan"), device="cuda").to(dt)
+        hip.conv2d_mfma([dict(srcs=[x], dst=y, ps=True)], wp, 3, 256, hip.BF16, bias=bp, act=hip.ACT_PRELU, slope_t=slope_t,
+                        pixel_shuffle=True)
+        torch.cuda.synchronize()
+        assert hip.lib().fcvsr_last_conv_kernel().decode().startswith("conv3_res" if mode == "1" else "conv_mfma")
+        outs.append(y.clone())
+    monkeypatch.delenv("FCVSR_MFMA_RES")
+    assert not torch.isnan(outs[0].float()).any() and torch.equal(outs[0], outs[1])

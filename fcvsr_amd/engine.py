@@ -167,6 +167,16 @@ class Engine:
             self._packed[key] = tab.to(dt).contiguous()
         return self._packed[key]
 
+    def _last_weights(self, name, dt, cimg):
+        """conv_last0 (cimg, cin, 3, 3) as the [16 or 32][cin] table of fcvsr_conv_last: row = tap * cimg + c, zero rows past 9 cimg."""
+        key = (name, "last", dt)
+        if key not in self._packed:
+            w = self._par[name + ".weight"].detach()             # (cimg, cin, 3, 3)
+            tab = torch.zeros(16 if cimg == 1 else 32, w.shape[1], device=w.device, dtype=torch.float32)
+            tab[:9 * cimg] = w.permute(2, 3, 0, 1).reshape(9 * cimg, w.shape[1])      # (ky, kx, c, cin)
+            self._packed[key] = tab.to(dt).contiguous()
+        return self._packed[key]
+
     def _tdt(self):
         """Storage dtype of the SCNetbk trunk (x, t2, R, cross-scale terms, block outputs): f32, or - with
         model.trunk16 in the 16-bit modes - the MFMA operand dtype (halves the bytes and the staging instructions of
@@ -678,7 +688,7 @@ class Engine:
             self._refresh(dev)
             ns = max(1, min(int(getattr(m, "streams", 1)), B))
             flags = tuple(bool(getattr(m, f, True)) for f in ("trunk16", "fold_f1", "fuse_tail", "pool_first", "fuse_freq_mlp",
-                                                              "fuse_freq_head", "fast_feat", "fuse_rcb_tail", "gc_separate"))
+                                                              "fuse_freq_head", "fast_feat", "fuse_rcb_tail", "gc_separate", "fast_last"))
             cfg = (tuple(x.shape[1:]), self.precision, str(dev), self._pack_epoch, flags)
             if ns > 1 and cfg not in self._warm:
                 # First pass of a configuration: re-packed weights, band masks and per-kernel attributes are created lazily
@@ -828,7 +838,14 @@ class Engine:
         else:
             u2 = self._new(dev, B, 4 * H, 4 * W, n, dtype=self._adt())
             self._conv("upconv2", [u1], u2, act=ACT_PRELU, slope_t=a_t, ps=True)
-            self._conv("conv_last0", [u2], out_v, res=[out_v])
+            if self.precision != "f32" and n == 64 and Cimg <= 3 and getattr(m, "fast_last", True):
+                # 3x3 up-convs (full / RGB models): conv_last0 as a memory-bound "taps are MFMA columns" pass over u2
+                wl = self._last_weights("conv_last0", self._adt(), Cimg)
+                u2v = view(u2)
+                check(L.fcvsr_conv_last(C.byref(u2v), wl.data_ptr(), ptr(self._par.get("conv_last0.bias")), B, 4 * H, 4 * W, Cimg,
+                                        C.byref(ov), st), "fcvsr_conv_last")
+            else:
+                self._conv("conv_last0", [u2], out_v, res=[out_v])
         if self.taps is not None:
             self.taps["out"] = out.clone()
         return out

@@ -115,6 +115,7 @@ SIGNATURES = {
     "fcvsr_pixel_shuffle": [_VP, _VP, _I, _I, _I, _I, _VP],
     "fcvsr_bilinear_up4": [_PV, _I, _I, _I, _PV, _VP],
     "fcvsr_tail_fused": [_PV, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _PV, _VP],
+    "fcvsr_conv_last": [_PV, _VP, _VP, _I, _I, _I, _I, _PV, _VP],
 }
 _RESTYPES = {"fcvsr_last_error": C.c_char_p, "fcvsr_last_conv_kernel": C.c_char_p, "fcvsr_conv2d_wgrad_scratch_elems": C.c_longlong,
              "fcvsr_conv2d_wgrad_mfma_scratch_elems": C.c_longlong}

@@ -298,6 +298,10 @@ int fcvsr_bilinear_up4(const fcvsr_view* src, int B, int H, int W, const fcvsr_v
  * holds the bilinear base skip).  The (B,2*H2,2*W2,64) intermediate is never stored. */
 int fcvsr_tail_fused(const fcvsr_view* u1, const void* w2, const float* b2, const float* slope, const void* wl,
                      const float* bl, int B, int H2, int W2, const fcvsr_view* out, void* stream);
+/* conv_last0 alone (:2607 / :2683; the RGB twins' 3-channel variant): out += bias + conv3x3(u), u (B,H,W,64) dense 16-bit at the
+ * OUTPUT resolution, out a (B,H,W,C) f32 view (any strides: the NCHW result), C = 1..3.  w: [16 (C = 1) or 32][64] in u's dtype,
+ * row tap*C + c (tap = ky*3 + kx), zero rows past 9C.  Used where fcvsr_tail_fused does not apply (3x3 up-convs). */
+int fcvsr_conv_last(const fcvsr_view* u, const void* w, const float* bias, int B, int H, int W, int C, const fcvsr_view* out, void* stream);
 
 #ifdef __cplusplus
 }

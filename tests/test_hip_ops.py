@@ -614,3 +614,26 @@ def test_conv_resident_weights_pixel_shuffle_matches_generic(monkeypatch):
         outs.append(y.clone())
     monkeypatch.delenv("FCVSR_MFMA_RES")
     assert not torch.isnan(outs[0].float()).any() and torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("cimg", [1, 3])
+def test_conv_last_kernel_vs_f32_reference(cimg):
+    """fcvsr_conv_last (3x3, 64 -> 1 or 3 channels, taps as MFMA columns, read-modify-write of the NCHW result) against torch's f32
+    convolution of the same bf16-rounded operands: bf16 products are exact in f32, only the summation order differs."""
+    import ctypes as C
+    from fcvsr_amd import hip
+    g0 = torch.Generator().manual_seed(40 + cimg)
+    B, H, W = 2, 21, 45                                      # partial tiles in both directions
+    u = torch.randn(B, H, W, 64, generator=g0).to(torch.bfloat16)
+    w = (torch.randn(cimg, 64, 3, 3, generator=g0) / 24.0).to(torch.bfloat16)
+    bias = torch.randn(cimg, generator=g0)
+    base = torch.randn(B, cimg, H, W, generator=g0)
+    ref = base + torch.nn.functional.conv2d(u.float().permute(0, 3, 1, 2), w.float(), bias, padding=1)
+    tab = torch.zeros(16 if cimg == 1 else 32, 64)
+    tab[:9 * cimg] = w.float().permute(2, 3, 0, 1).reshape(9 * cimg, 64)
+    out = base.clone().cuda()
+    ud, td, bd = u.cuda(), tab.to(torch.bfloat16).cuda(), bias.cuda()
+    uv, ov = hip.view(ud), hip.view(out.permute(0, 2, 3, 1))
+    hip.check(hip.lib().fcvsr_conv_last(C.byref(uv), td.data_ptr(), bd.data_ptr(), B, H, W, cimg, C.byref(ov), hip.stream_ptr()), "conv_last")
+    torch.cuda.synchronize()
+    assert float((out.cpu() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))

@@ -512,6 +512,79 @@ __global__ void xscale_levels_kernel(XsArgs a, int Cq) {
   stq<DT, V>(L.out, t, acc);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Level 0 of BlockRCB's second half in one pass (16-bit storage modes).  The generic sequence writes R0 = lrelu(r + add) + z
+// (gc_apply_levels) and reads it back for out0 = x + 2 R0 + up2(up.0(R1)) (xscale_levels); at the full-resolution level that
+// round trip is the largest elementwise cost of the block.  R0 is needed by nobody else: the down path only wants its 2x2
+// average.  Thread = (2x2 pixel block, 8 channels): it forms the four R0 values (rounded to the storage type exactly where
+// the two-kernel path stores them, so results are bit-identical), writes their average P0 and the four finished outputs.
+// The bilinear x2 up-sample (align_corners=False) of a 2x2 block touches the 3x3 neighbourhood of the half-resolution source.
+struct Rcb0Args {
+  const void* x; const void* r; const float* add; const void* z; const void* up; void* out; void* pool;
+  float slope, rs;
+  int B, H, W;
+};
+
+template <int DT>
+__global__ void __launch_bounds__(256) rcb_level0_kernel(Rcb0Args a, int Cq) {      // Cq = C / 8
+  const int H2 = a.H >> 1, W2 = a.W >> 1;
+  const long long total = (long long)a.B * H2 * W2 * Cq;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int cq = (int)(t % Cq);
+  const long long pg = t / Cq;
+  const int x2 = (int)(pg % W2), y2 = (int)((pg / W2) % H2), b = (int)(pg / ((long long)W2 * H2));
+  const float* ad = a.add + (long long)b * Cq * 8 + cq * 8;
+  const float4 ad0 = *reinterpret_cast<const float4*>(ad), ad1 = *reinterpret_cast<const float4*>(ad + 4);
+  const long long q00 = (((long long)b * a.H + 2 * y2) * a.W + 2 * x2) * Cq + cq;
+  const long long qs[4] = {q00, q00 + Cq, q00 + (long long)a.W * Cq, q00 + (long long)a.W * Cq + Cq};
+  QuadV<2> rr[4], zz[4], xx[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { rr[i] = ldq<DT, 2>(a.r, qs[i]); zz[i] = ldq<DT, 2>(a.z, qs[i]); xx[i] = ldq<DT, 2>(a.x, qs[i]); }
+  // 3 x 3 neighbourhood of the half-resolution up source, indices clamped like upsample_bilinear2d's y1 / x1
+  const int ys[3] = {y2 > 0 ? y2 - 1 : 0, y2, y2 < H2 - 1 ? y2 + 1 : y2};
+  const int xs[3] = {x2 > 0 ? x2 - 1 : 0, x2, x2 < W2 - 1 ? x2 + 1 : x2};
+  QuadV<2> U[3][3];
+  const long long u0 = ((long long)b * H2 * W2) * Cq + cq;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) U[i][j] = ldq<DT, 2>(a.up, u0 + ((long long)ys[i] * W2 + xs[j]) * Cq);
+  QuadV<2> R[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float4 av = h ? ad1 : ad0, rv = rr[i].p[h], zv = zz[i].p[h];
+      float4 v = make_float4(rv.x + av.x, rv.y + av.y, rv.z + av.z, rv.w + av.w);
+      v.x = v.x >= 0.f ? v.x : v.x * a.slope; v.y = v.y >= 0.f ? v.y : v.y * a.slope;
+      v.z = v.z >= 0.f ? v.z : v.z * a.slope; v.w = v.w >= 0.f ? v.w : v.w * a.slope;
+      R[i].p[h] = as_stored<DT>(make_float4(v.x + zv.x, v.y + zv.y, v.z + zv.z, v.w + zv.w));
+    }
+  }
+  {
+    const QuadV<2> top = qv_half_sum<2>(R[0], R[1]), bot = qv_half_sum<2>(R[2], R[3]);
+    stq<DT, 2>(a.pool, t, qv_half_sum<2>(top, bot));
+  }
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) {
+    // even output row 2 y2: source y = y2 - 0.25 (clamped at 0); odd row: y2 + 0.25
+    const float ly = dy ? 0.25f : (y2 > 0 ? 0.75f : 0.f);
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const float lx = dx ? 0.25f : (x2 > 0 ? 0.75f : 0.f);
+      const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+      QuadV<2> acc = qv_axpy<2>(a.rs, R[dy * 2 + dx], xx[dy * 2 + dx]);
+      acc = qv_axpy<2>(w00, U[dy][dx], acc);
+      acc = qv_axpy<2>(w01, U[dy][dx + 1], acc);
+      acc = qv_axpy<2>(w10, U[dy + 1][dx], acc);
+      acc = qv_axpy<2>(w11, U[dy + 1][dx + 1], acc);
+      stq<DT, 2>(a.out, qs[dy * 2 + dx], acc);
+    }
+  }
+}
+
 }  // namespace fcvsr
 
 using namespace fcvsr;
@@ -586,6 +659,25 @@ extern "C" int fcvsr_xscale(const void* x, const void* r, float r_scale, const v
   else
     hipLaunchKernelGGL((xscale_kernel<FCVSR_F16>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, r, r_scale, dn,
                        up, out, B, H, W, C / 4);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fcvsr_rcb_level0(const void* x, const void* r, const float* add, const void* z, const void* up, void* out,
+                                void* pool, float slope, float r_scale, int io_dtype, int B, int H, int W, int C, void* stream) {
+  FCVSR_CHECK_ARG(x && r && add && z && up && out && pool, "null pointer");
+  FCVSR_CHECK_ARG(io_dtype == FCVSR_BF16 || io_dtype == FCVSR_F16, "16-bit storage modes only");
+  FCVSR_CHECK_ARG(B > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, "even H, W required");
+  FCVSR_CHECK_ARG(C > 0 && C % 8 == 0, "C%8==0 required");
+  FCVSR_CHECK_ARG(al16(x) && al16(r) && al16(z) && al16(up) && al16(out) && al16(pool) && al16(add), "16-byte alignment");
+  FCVSR_CHECK_ARG(out != x && out != r && out != z && out != up && pool != r && pool != z && pool != x && pool != up,
+                  "outputs must not alias inputs (neighbouring threads read the same up pixels)");
+  Rcb0Args a{x, r, add, z, up, out, pool, slope, r_scale, B, H, W};
+  const long long total = (long long)B * (H / 2) * (W / 2) * (C / 8);
+  if (io_dtype == FCVSR_BF16)
+    hipLaunchKernelGGL((rcb_level0_kernel<FCVSR_BF16>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, a, C / 8);
+  else
+    hipLaunchKernelGGL((rcb_level0_kernel<FCVSR_F16>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, a, C / 8);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

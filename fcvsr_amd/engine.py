@@ -623,8 +623,11 @@ class Engine:
         for l in range(3):
             fl[l].partial, fl[l].add, fl[l].nparts = parts[l].data_ptr(), adds[l].data_ptr(), nparts[l]
         check(L.fcvsr_gc_finish_levels(fl, 3, w1g.data_ptr(), w2g.data_ptr(), B, n, st), "fcvsr_gc_finish_levels")
-        R = [torch.empty_like(t) for t in t2]
         P = [self._new(dev, B, xs[l].shape[1] // 2, xs[l].shape[2] // 2, n, dtype=tdt) for l in (0, 1)]
+        if (getattr(m, "fuse_rcb_l0", True) and tdt != torch.float32 and rr[0].dtype == tdt and xs[0].dtype == tdt
+                and n % 8 == 0):
+            return self._block_rcb_tail_l0(pre, xs, t2, rr, adds, P, tdt)
+        R = [torch.empty_like(t) for t in t2]
         al = (hip.GcApplyLevel * 3)()
         for l in range(3):
             al[l].r, al[l].add, al[l].z, al[l].out = rr[l].data_ptr(), adds[l].data_ptr(), t2[l].data_ptr(), R[l].data_ptr()
@@ -645,6 +648,42 @@ class Engine:
             xl[l].dn_pooled = 1
             xl[l].B, xl[l].H, xl[l].W = B, xs[l].shape[1], xs[l].shape[2]
         check(L.fcvsr_xscale_levels(xl, 3, code, n, st), "fcvsr_xscale_levels")
+        return outs
+
+    def _block_rcb_tail_l0(self, pre, xs, t2, rr, adds, P, tdt):
+        """Same result as the generic sequence above (bit for bit), with level 0's R never stored: levels 1 and 2 go through
+        gc_apply / xscale as before, level 0 through fcvsr_rcb_level0 once up.0(R1) exists (832 -> 576 bytes per level-0
+        pixel at 64 channels)."""
+        m = self._model()
+        n = m.n_feats
+        L = lib()
+        st = stream_ptr()
+        B = xs[0].shape[0]
+        code = self._code(tdt)
+        R = [None, torch.empty_like(t2[1]), torch.empty_like(t2[2])]
+        al = (hip.GcApplyLevel * 3)()
+        for i, l in enumerate((1, 2)):
+            al[i].r, al[i].add, al[i].z, al[i].out = rr[l].data_ptr(), adds[l].data_ptr(), t2[l].data_ptr(), R[l].data_ptr()
+            al[i].pool = P[1].data_ptr() if l == 1 else None
+            al[i].B, al[i].H, al[i].W = B, xs[l].shape[1], xs[l].shape[2]
+        check(L.fcvsr_gc_apply_levels(al, 2, code, code, 0.2, n, st), "fcvsr_gc_apply_levels")
+        up = [torch.empty_like(R[l]) for l in (1, 2)]
+        self._convg(pre + ".up.0", [dict(srcs=[R[l]], dst=up[l - 1]) for l in (1, 2)])
+        outs = [torch.empty_like(x) for x in xs]
+        check(L.fcvsr_rcb_level0(xs[0].data_ptr(), rr[0].data_ptr(), adds[0].data_ptr(), t2[0].data_ptr(), up[0].data_ptr(),
+                                 outs[0].data_ptr(), P[0].data_ptr(), 0.2, 2.0, code, B, xs[0].shape[1], xs[0].shape[2], n, st),
+              "fcvsr_rcb_level0")
+        dn = [torch.empty_like(P[l]) for l in (0, 1)]
+        self._convg(pre + ".down.0", [dict(srcs=[P[l]], dst=dn[l]) for l in (0, 1)])
+        xl = (hip.XscaleLevel * 3)()
+        for i, l in enumerate((1, 2)):
+            xl[i].x, xl[i].r, xl[i].out = xs[l].data_ptr(), R[l].data_ptr(), outs[l].data_ptr()
+            xl[i].dn = dn[l - 1].data_ptr()
+            xl[i].up = up[1].data_ptr() if l == 1 else None
+            xl[i].r_scale = 2.0 if l == 2 else 1.0
+            xl[i].dn_pooled = 1
+            xl[i].B, xl[i].H, xl[i].W = B, xs[l].shape[1], xs[l].shape[2]
+        check(L.fcvsr_xscale_levels(xl, 2, code, n, st), "fcvsr_xscale_levels")
         return outs
 
     def _scnet(self, xs):
@@ -688,7 +727,8 @@ class Engine:
             self._refresh(dev)
             ns = max(1, min(int(getattr(m, "streams", 1)), B))
             flags = tuple(bool(getattr(m, f, True)) for f in ("trunk16", "fold_f1", "fuse_tail", "pool_first", "fuse_freq_mlp",
-                                                              "fuse_freq_head", "fast_feat", "fuse_rcb_tail", "gc_separate", "fast_last"))
+                                                              "fuse_freq_head", "fast_feat", "fuse_rcb_tail", "gc_separate", "fast_last",
+                                                              "fuse_rcb_l0"))
             cfg = (tuple(x.shape[1:]), self.precision, str(dev), self._pack_epoch, flags)
             if ns > 1 and cfg not in self._warm:
                 # First pass of a configuration: re-packed weights, band masks and per-kernel attributes are created lazily

@@ -112,6 +112,7 @@ SIGNATURES = {
     "fcvsr_gc_partial_levels": [C.POINTER(GcPartialLevel), _I, _I, _VP, _I, _VP],
     "fcvsr_gc_apply_levels": [C.POINTER(GcApplyLevel), _I, _I, _I, _F, _I, _VP],
     "fcvsr_xscale_levels": [C.POINTER(XscaleLevel), _I, _I, _I, _VP],
+    "fcvsr_rcb_level0": [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _F, _F, _I, _I, _I, _I, _I, _VP],
     "fcvsr_pixel_shuffle": [_VP, _VP, _I, _I, _I, _I, _VP],
     "fcvsr_bilinear_up4": [_PV, _I, _I, _I, _PV, _VP],
     "fcvsr_tail_fused": [_PV, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _PV, _VP],

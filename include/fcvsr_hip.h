@@ -273,6 +273,15 @@ typedef struct {
 } fcvsr_xscale_level;
 int fcvsr_xscale_levels(const fcvsr_xscale_level* lv, int n_levels, int io_dtype, int C, void* stream);
 
+/* Full-resolution level of BlockRCB's second half in one pass (reference CVSR_freq.py:722-725 + :766-777, level 0; 16-bit
+ * storage modes):  R = lrelu(r + add[b], slope) + z  is formed in registers (rounded to the storage type, as the two-kernel
+ * sequence fcvsr_gc_apply_levels -> fcvsr_xscale_levels stores it: results are bit-identical to that sequence),
+ *   pool = avg_pool2x2(R)            [B, H/2, W/2, C]   (input of down.0, which commutes with the pooling)
+ *   out  = x + r_scale * R + bilinear_x2(up)            (up = up.0(R of level 1), [B, H/2, W/2, C], align_corners=False)
+ * x, r, z, up, out, pool are NHWC in io_dtype (FCVSR_BF16 / FCVSR_F16), add is f32 [B, C]; C % 8 == 0, H and W even. */
+int fcvsr_rcb_level0(const void* x, const void* r, const float* add, const void* z, const void* up, void* out, void* pool,
+                     float slope, float r_scale, int io_dtype, int B, int H, int W, int C, void* stream);
+
 /* ---- tail ------------------------------------------------------------------------------------------------------ */
 /* nn.PixelShuffle(2) of a dense NHWC tensor (B,H,W,C) -> (B,2H,2W,C/4) (:2634-2635) */
 /* ContextBlock softmax-pool partials (:657-701) from a STORED 16-bit r, all pyramid levels in one launch: one [C+2] record per

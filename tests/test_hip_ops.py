@@ -637,3 +637,47 @@ def test_conv_last_kernel_vs_f32_reference(cimg):
     hip.check(hip.lib().fcvsr_conv_last(C.byref(uv), td.data_ptr(), bd.data_ptr(), B, H, W, cimg, C.byref(ov), hip.stream_ptr()), "conv_last")
     torch.cuda.synchronize()
     assert float((out.cpu() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("H,W", [(22, 70), (2, 2), (36, 64)])
+def test_rcb_level0_equals_apply_then_xscale(dt, H, W):
+    """fcvsr_rcb_level0 (R0 never stored) against the two-kernel sequence fcvsr_gc_apply_levels -> fcvsr_xscale_levels it
+    replaces at the full-resolution level (reference BlockRCB :722-725, :766-777): bit-identical out and pooled R, including
+    the clamped borders of the bilinear x2 up-sample; plus an f64 restatement of the formula as an independent check."""
+    from fcvsr_amd import hip
+    L = hip.lib()
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    code = hip.BF16 if dt == "bf16" else hip.F16
+    g0 = torch.Generator().manual_seed(H * 100 + W)
+    B, n = 2, 64
+    mk = lambda h, w: torch.randn(B, h, w, n, generator=g0).cuda().to(tdt)
+    x, r, z, up = mk(H, W), mk(H, W), mk(H, W), mk(H // 2, W // 2)
+    add = torch.randn(B, n, generator=g0).cuda()
+    st = hip.stream_ptr()
+    # two-kernel sequence
+    R = torch.empty_like(x); P_ref = torch.empty(B, H // 2, W // 2, n, device="cuda", dtype=tdt); out_ref = torch.empty_like(x)
+    al = (hip.GcApplyLevel * 3)()
+    al[0].r, al[0].add, al[0].z, al[0].out, al[0].pool = r.data_ptr(), add.data_ptr(), z.data_ptr(), R.data_ptr(), P_ref.data_ptr()
+    al[0].B, al[0].H, al[0].W = B, H, W
+    hip.check(L.fcvsr_gc_apply_levels(al, 1, code, code, 0.2, n, st), "gc_apply_levels")
+    xl = (hip.XscaleLevel * 3)()
+    xl[0].x, xl[0].r, xl[0].out, xl[0].dn, xl[0].up = x.data_ptr(), R.data_ptr(), out_ref.data_ptr(), None, up.data_ptr()
+    xl[0].r_scale, xl[0].dn_pooled, xl[0].B, xl[0].H, xl[0].W = 2.0, 1, B, H, W
+    hip.check(L.fcvsr_xscale_levels(xl, 1, code, n, st), "xscale_levels")
+    # one pass
+    P = torch.full_like(P_ref, float("nan")); out = torch.full_like(x, float("nan"))
+    hip.check(L.fcvsr_rcb_level0(x.data_ptr(), r.data_ptr(), add.data_ptr(), z.data_ptr(), up.data_ptr(), out.data_ptr(),
+                                 P.data_ptr(), 0.2, 2.0, code, B, H, W, n, st), "rcb_level0")
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), out_ref.view(torch.int16))
+    assert torch.equal(P.view(torch.int16), P_ref.view(torch.int16))
+    # independent f64 formula
+    v = r.double() + add.double()[:, None, None, :]
+    Rd = (torch.where(v >= 0, v, 0.2 * v).float() + z.float()).to(tdt).double()
+    upd = F.interpolate(up.double().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    ref = x.double() + 2.0 * Rd + upd
+    tol = (2.0 ** -8 if dt == "bf16" else 2.0 ** -11) * float(ref.abs().max())
+    assert float((out.double() - ref).abs().max()) <= tol
+    pd = F.avg_pool2d(Rd.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    assert float((P.double() - pd).abs().max()) <= (2.0 ** -8 if dt == "bf16" else 2.0 ** -11) * float(pd.abs().max())

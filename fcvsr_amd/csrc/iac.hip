@@ -277,6 +277,7 @@ struct IacArgs {
   const float* kbias;     // ... and their bias
   float slope;
   int B, H, W, tiles_x, tiles_y;
+  int ntiles;             // B * tiles_x * tiles_y: the persistent workgroups of iac_step64_kernel split this range
 };
 
 constexpr int kKtRow = 3 * kJC + 8;                   // halfwords per pixel row of the predicted-kernel tile in LDS
@@ -289,22 +290,85 @@ constexpr int kKtRow = 3 * kJC + 8;                   // halfwords per pixel row
 // (192 x 64) x (64 x 72): 18 MFMA tiles spread over the 4 waves, operands straight from L2 (weights) / HBM (the 64-channel
 // predictor features), result rounded to the MFMA dtype into LDS - exactly what the stand-alone F[1] launch would have
 // stored, minus 1152 bytes written and 2 x 1152 bytes read per pixel and iteration set.
+#ifndef FCVSR_IAC_PIPE
+#define FCVSR_IAC_PIPE 1
+#endif
+// Persistent workgroups (the host launches two per CU): each walks a contiguous run of tiles, so the predictor weights of
+// its waves (FK: 4 or 8 MFMA A-fragments) and the bias are fetched once per workgroup instead of once per tile (24 KB per
+// tile was a quarter of what a tile pulled through L2), and consecutive tiles of a workgroup share their halo columns in L1.
 template <int KDT, int ADT, int ND, bool FK>
 __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
+  constexpr bool PIPE = FCVSR_IAC_PIPE != 0;
   const View k1 = a.k1;
   const float slope = a.slope;
   const int H = a.H, W = a.W, tiles_x = a.tiles_x, tiles_y = a.tiles_y;
-  __shared__ __align__(16) float s_s[kIHY * kIHX * kJC];
-  __shared__ __align__(16) float v_s[kIY * kIHX * kJC];
-  __shared__ __align__(16) uint16_t kt_s[FK ? kIY * kIHX * kKtRow : 8];
-  const int tid = threadIdx.x;
-  const int oct = tid & 7, ps = tid >> 3;              // 8-channel group, pixel slot (32 per pass)
-  const int c0 = blockIdx.y * kJC + oct * 8;
-  int t = blockIdx.x;
+  // LDS: the warped tile s (6 x 18 pixels) and the vertical result v (4 x 18), f32, 64 channels each (46,080 bytes).  The
+  // predicted-kernel tile (FK, 28,800 bytes) lives in s's bytes (+1,152 of its own): it is written by the GEMM, copied into
+  // the owning lanes' registers and dead before the first warped value is stored (two barriers, see below).  FK adds the
+  // predictor's 192 x 64 weights (rows padded to 144 bytes: the 16 rows of a ds_read_b128 lane group fall on 16 different
+  // slots) and bias, resident for the workgroup's whole tile run: 75,648 bytes, two workgroups per CU.
+  constexpr int kSBytes = kIHY * kIHX * kJC * 4, kVBytes = kIY * kIHX * kJC * 4, kKtBytes = kIY * kIHX * kKtRow * 2;
+  constexpr int kWRow = kJC + 8, kWBytes = FK ? 3 * kJC * kWRow * 2 : 0, kKbBytes = FK ? 3 * kJC * 4 : 0;
+  constexpr int kS2Bytes = FK && kKtBytes > kSBytes ? kKtBytes : kSBytes;      // s_s and kt_s share these bytes, v_s does not
+  __shared__ __align__(16) unsigned char smem[kS2Bytes + kVBytes + kWBytes + kKbBytes];
+  float* const s_s = reinterpret_cast<float*>(smem);
+  float* const v_s = reinterpret_cast<float*>(smem + kS2Bytes);
+  uint16_t* const kt_s = reinterpret_cast<uint16_t*>(smem);
+  uint16_t* const w_s = reinterpret_cast<uint16_t*>(smem + kS2Bytes + kVBytes);
+  float* const kb_s = reinterpret_cast<float*>(smem + kS2Bytes + kVBytes + kWBytes);
+  // s / v pixel records are 64 floats = one 256-byte bank row.  A lane's 8 channels are kept as two 16-byte halves 128
+  // bytes apart ([half][oct][4]) with the halves swapped on odd pixels: the 8 lanes of a pixel then write 128 contiguous
+  // bytes per store, and the four pixels x four lane-quads of a ds_read_b128 group land on 16 different slots (the plain
+  // [oct][8] record put lanes l and l+4 of every store and two of the four pixels of every read group on the same banks).
+  constexpr bool BF = KDT == FCVSR_BF16;
+  int t_begin, t_end;
   {                                                    // workgroups go round-robin to the 8 XCDs: give each XCD a contiguous
-    const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = t & 7, loc = t >> 3;   // run of tiles so halos hit its L2
-    t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+    const int g = blockIdx.x;                          // run of tiles so halos hit its L2
+    const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = g & 7, loc = g >> 3;
+    const int ci = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+    t_begin = (int)((long long)ci * a.ntiles / nwg);
+    t_end = (int)((long long)(ci + 1) * a.ntiles / nwg);
   }
+  if (FK) {                                            // predictor weights and bias: once per workgroup
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 3 * kJC * kJC / 8 / 256; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 3, seg = idx & 7;
+      *reinterpret_cast<uint4*>(w_s + row * kWRow + seg * 8) = *reinterpret_cast<const uint4*>(a.wk + row * kJC + seg * 8);
+    }
+    if (tid < 3 * kJC) kb_s[tid] = a.kbias[tid];
+    __syncthreads();
+  }
+  // The offsets head the longest dependency chain of a tile (offsets -> tap addresses -> gather -> warp).  A persistent
+  // workgroup also pays for its own stores: vmcnt retires in order, so the first wait of a tile would sit behind the previous
+  // tile's output stores.  The next tile's offsets are therefore requested before those stores are issued.
+  auto load_off = [&](const int tt, const int tidv) {
+    const int lanev = tidv & 63, wavev = tidv >> 6;
+    const int bb = tt / (tiles_x * tiles_y), tt2 = tt - bb * tiles_x * tiles_y;
+    const int oy0 = (tt2 / tiles_x) * kIY, ox0 = (tt2 % tiles_x) * kIX;
+    const int sdir = (lanev >> 5) < ND ? (lanev >> 5) : 0, sit = (lanev >> 3) & 3, spl = lanev & 7;
+    int hp = sit * 32 + wavev * 8 + spl;
+    hp = hp < kIHY * kIHX ? hp : kIHY * kIHX - 1;
+    const int hy = hp / kIHX, hx = hp - hy * kIHX;
+    int gy = oy0 + hy - 1, gx = ox0 + hx - 1;
+    gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
+    gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
+    const View off = a.d[sdir].off;
+    const float* op = off.p + (long long)bb * off.sb + (long long)gy * off.sy + (long long)gx * off.sx;
+    return make_float2(op[0], op[off.sc]);
+  };
+  float2 off_next = make_float2(0.f, 0.f);
+  if (t_begin < t_end) off_next = load_off(t_begin, threadIdx.x);
+  for (int t = t_begin; t < t_end; ++t) {
+  // Everything derived from the lane id is recomputed per tile (a handful of VALU ops): hoisted out of the loop these
+  // values - LDS record offsets, channel offsets, fragment rows - cost two dozen registers the tile body has no room for
+  // (hipcc spilled them to scratch).  The empty asm makes the id opaque, so nothing below is loop-invariant.
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int oct = tid & 7, ps = tid >> 3;              // 8-channel group, pixel slot (32 per pass)
+  auto rec = [&](const int pix, const int h) { return pix * kJC + ((h ^ (pix & 1)) << 5) + oct * 4; };
+  const int c0 = blockIdx.y * kJC + oct * 8;
+  const int lane = tid & 63, wave = tid >> 6, mr = lane & 31, hh = lane >> 5;
   const int b = t / (tiles_x * tiles_y);
   const int t2 = t - b * tiles_x * tiles_y;
   const int ty0 = (t2 / tiles_x) * kIY, tx0 = (t2 % tiles_x) * kIX;
@@ -330,12 +394,9 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
     }
   }
   // ---- kernel-predictor GEMM (FK): D[cout][pixel] = W[cout][:] . k0[pixel][:] + bias, 6 cout tiles x 3 pixel tiles.
-  // Wave w owns cout tile w for all three pixel tiles; waves 0 and 1 also take cout tiles 4 and 5.  Every operand load
-  // (12 pixel fragments + 4 or 8 weight fragments) is issued here in one batch; the MFMAs run after the warp phase of the
-  // first direction has issued its own loads, so the two latencies overlap.
-  constexpr bool BF = KDT == FCVSR_BF16;
-  const int lane = tid & 63, wave = tid >> 6, mr = lane & 31, hh = lane >> 5;
-  uint4 kf[3][4], wf[2][4];
+  // The 12 pixel fragments are requested here, with the offsets; the MFMAs run after the first direction's taps have been
+  // issued, so the gather latency hides behind them.
+  uint4 kf[3][4];
   if (FK) {
     const uint16_t* k0p = reinterpret_cast<const uint16_t*>(a.k0.p) + (long long)b * a.k0.sb + hh * 8;
 #pragma unroll
@@ -350,31 +411,27 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) kf[nt][kk] = *reinterpret_cast<const uint4*>(kp + kk * 16);
     }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int mt = wave + 4 * q;                     // q = 1 exists for waves 0 and 1 only
-      const uint16_t* wp = a.wk + ((mt < 6 ? mt : wave) * 32 + mr) * kJC + hh * 8;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) wf[q][kk] = *reinterpret_cast<const uint4*>(wp + kk * 16);
-    }
   }
   auto predictor_gemm = [&]() {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int mt = wave + 4 * q;
-      if (mt < 6) {                                    // wave-uniform
+      if (mt < 6) {                                    // wave-uniform: wave w owns cout tile w, waves 0 and 1 also 4 and 5
+        uint4 wfr[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) wfr[kk] = *reinterpret_cast<const uint4*>(w_s + (mt * 32 + mr) * kWRow + hh * 8 + kk * 16);
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) {
           f32x16_t acc;
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) acc = mfma<BF>(wf[q][kk], kf[nt][kk], acc);
+          for (int kk = 0; kk < 4; ++kk) acc = mfma<BF>(wfr[kk], kf[nt][kk], acc);
           const int p = nt * 32 + mr;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int co = mt * 32 + 8 * g + 4 * hh;   // acc[4g..4g+3] = couts co..co+3 of pixel column mr
-            const float4 b4 = *reinterpret_cast<const float4*>(a.kbias + co);
+            const float4 b4 = *reinterpret_cast<const float4*>(kb_s + co);
             const uint2 pk = cvt4<BF>(make_float4(acc[4 * g] + b4.x, acc[4 * g + 1] + b4.y, acc[4 * g + 2] + b4.z, acc[4 * g + 3] + b4.w));
             if (p < kIY * kIHX) *reinterpret_cast<uint2*>(kt_s + p * kKtRow + co) = pk;
           }
@@ -402,10 +459,9 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
     int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
     gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
     gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
-    const View off = a.d[sdir].off, prev = a.d[sdir].prev;
-    const float* op = off.p + (long long)b * off.sb + (long long)gy * off.sy + (long long)gx * off.sx;
-    const float fx = (float)gx + op[0];
-    const float fy = (float)gy + op[off.sc];
+    const View prev = a.d[sdir].prev;
+    const float fx = (float)gx + off_next.x;
+    const float fy = (float)gy + off_next.y;
     const float x0f = floorf(fx), y0f = floorf(fy);
     const float wx1 = fx - x0f, wy1 = fy - y0f;
     const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
@@ -424,9 +480,8 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
       }
     }
   }
-  Pack8<ADT> fpk[ND][2];
-#pragma unroll
-  for (int dir = 0; dir < ND; ++dir) {
+  Pack8<ADT> fpk[ND][2];                               // feat_in of the lane's two interior pixels (consumed in phase 3)
+  auto issue_fin = [&](const int dir) {
     const View fin = a.d[dir].fin;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -436,13 +491,12 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
       gx = gx > W - 1 ? W - 1 : gx;
       fpk[dir][j] = ld_p8<ADT>(fin.p, (long long)b * fin.sb + (long long)gy * fin.sy + (long long)gx * fin.sx + c0);
     }
-  }
-  if (FK) predictor_gemm();                            // operands requested above, together with the offsets
+  };
+  issue_fin(0);
 
   // phase 1a: the 4 x NP bilinear taps of a direction (unconditional: out-of-image taps read a clamped address with
   // weight 0); addresses and weights come from the slot owner's registers
   Pack8<ADT> tap[ND][NP][4];
-  float tw[ND][NP][4];
   auto issue_taps = [&](const int dir) {
     const View prev = a.d[dir].prev;
     const long long pp = (long long)b * prev.sb + c0;
@@ -453,7 +507,6 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
       const int src = dir * 32 + it * 8 + (lane >> 3);  // the lane that owns (dir, it, this lane's pixel)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        tw[dir][it][q] = __shfl(my_w[q], src);
         tap[dir][it][q] = ld_p8<ADT>(pb, __shfl(my_eo[q], src));
       }
     }
@@ -463,20 +516,23 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
 #pragma unroll
     for (int it = 0; it < NP; ++it) {
       const int hp = it * 32 + ps;
+      const int src = dir * 32 + it * 8 + (lane >> 3);
       float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float tw[4];                                      // fetched here, not with the addresses: 16 registers per direction
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tw[q] = __shfl(my_w[q], src);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float v[8];
         unpack8<ADT>(tap[dir][it][q], v);
         // out-of-image taps carry weight 0 (their clamped sample is a finite in-image value)
-        const float w = tw[dir][it][q];
+        const float w = tw[q];
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = fmaf(v[c], w, acc[c]);
       }
       if (hp < kIHY * kIHX) {
-        float* sp = s_s + hp * kJC + oct * 8;
-        *reinterpret_cast<float4*>(sp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        *reinterpret_cast<float4*>(sp + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        *reinterpret_cast<float4*>(s_s + rec(hp, 0)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(s_s + rec(hp, 1)) = make_float4(acc[4], acc[5], acc[6], acc[7]);
       }
     }
   };
@@ -495,15 +551,15 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt) {
-          const float* sp = s_s + ((y + tt) * kIHX + hx) * kJC + oct * 8;
-          const float4 va = *reinterpret_cast<const float4*>(sp), vb = *reinterpret_cast<const float4*>(sp + 4);
+          const int sp = (y + tt) * kIHX + hx;
+          const float4 va = *reinterpret_cast<const float4*>(s_s + rec(sp, 0)), vb = *reinterpret_cast<const float4*>(s_s + rec(sp, 1));
           const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
 #pragma unroll
           for (int c = 0; c < 8; ++c) acc[c] = fmaf(v[c], k[c * 3 + tt], acc[c]);
         }
-        float* vp = v_s + (y * kIHX + hx) * kJC + oct * 8;
-        *reinterpret_cast<float4*>(vp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        *reinterpret_cast<float4*>(vp + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        const int vp = y * kIHX + hx;
+        *reinterpret_cast<float4*>(v_s + rec(vp, 0)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(v_s + rec(vp, 1)) = make_float4(acc[4], acc[5], acc[6], acc[7]);
       }
     }
     __syncthreads();
@@ -520,8 +576,8 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt) {
-          const float* vp = v_s + (y * kIHX + x + tt) * kJC + oct * 8;
-          const float4 va = *reinterpret_cast<const float4*>(vp), vb = *reinterpret_cast<const float4*>(vp + 4);
+          const int vp = y * kIHX + x + tt;
+          const float4 va = *reinterpret_cast<const float4*>(v_s + rec(vp, 0)), vb = *reinterpret_cast<const float4*>(v_s + rec(vp, 1));
           const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
 #pragma unroll
           for (int c = 0; c < 8; ++c) acc[c] = fmaf(v[c], k[c * 3 + tt], acc[c]);
@@ -537,10 +593,9 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
   };
 
   issue_taps(0);
-  warp_store(0);
-  if (ND > 1) issue_taps(1);                           // in flight during direction 0's LDS phases
-  __syncthreads();
   if (FK) {                                            // the predicted kernels of the lane's pixels: LDS -> registers, once
+    predictor_gemm();                                  // kf requested before the taps: in flight since the tile began
+    __syncthreads();                                   // GEMM results of all four waves are in kt_s
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int p = j * 32 + ps;
@@ -551,13 +606,22 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
       const uint4* kq = reinterpret_cast<const uint4*>(kt_s + ((ps >> 1) * kIHX + ((ps & 1) ? kIHX - 1 : 0)) * kKtRow + oct * 24);
       khal.q[0] = kq[0]; khal.q[1] = kq[1]; khal.q[2] = kq[2];
     }
+    __syncthreads();                                   // kt_s is dead: its bytes become s_s / v_s
   }
+  warp_store(0);
+  if (ND > 1 && PIPE) { issue_taps(1); issue_fin(1); } // in flight during direction 0's LDS phases
+  if (t + 1 < t_end) off_next = load_off(t + 1, tid);
+  __syncthreads();
   sac_phases(0);
   if (ND > 1) {
     // s_s was last read in phase 2 of direction 0, which every wave has left (barrier inside sac_phases)
+    if (!PIPE) { issue_taps(1); issue_fin(1); }
     warp_store(1);
     __syncthreads();
     sac_phases(1);
+  }
+  // Next tile: s_s is rewritten (by kt_s in the FK case) after its last read (phase 2, before the barrier inside sac_phases);
+  // v_s is read until the end of phase 3 and rewritten in the next tile's phase 2, behind the barrier after its warp_store.
   }
 }
 
@@ -572,8 +636,31 @@ static bool quad_ok(const fcvsr_view* v, int dt) {
   return v->sx % g == 0 && v->sy % g == 0 && v->sb % g == 0 && ((uintptr_t)v->ptr % al) == 0;
 }
 
+static int iac_persistent_wgs() {                      // two workgroups per CU (registers and LDS allow exactly two)
+  static int n[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 512;
+  if (!n[dev]) {
+    hipDeviceProp_t prop;
+    n[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? 2 * prop.multiProcessorCount : 512;
+  }
+  return n[dev];
+}
+
 template <int KDT, int ND, bool FK = false>
-static void launch_iac64(int adt, dim3 grid, hipStream_t st, const IacArgs& a) {
+static void launch_iac64(int adt, dim3 grid, hipStream_t st, IacArgs a) {
+  a.ntiles = (int)grid.x;
+  // Tile runs pay off for the fused-predictor kernel only (its workgroups stage 24 KB of weights first: 384 -> 350 us per
+  // 16 x 180 x 320 iteration); the others lose 3-8 % to a run of any length (measured with 2...28 tiles per workgroup) and
+  // keep one tile per workgroup.  FCVSR_IAC_PERSIST: bit 0 = fused-predictor kernel, bit 1 = the others (experiments).
+  static const int persist = getenv("FCVSR_IAC_PERSIST") ? atoi(getenv("FCVSR_IAC_PERSIST")) : 1;
+  static const int tpw = getenv("FCVSR_IAC_TPW") ? atoi(getenv("FCVSR_IAC_TPW")) : 0;
+  if (persist & (FK ? 1 : 2)) {
+    int nwg = iac_persistent_wgs() / (int)grid.y;
+    if (tpw > 0) nwg = ((int)grid.x + tpw - 1) / tpw;
+    nwg = nwg < 8 ? 8 : nwg / 8 * 8;
+    if (nwg < (int)grid.x) grid.x = nwg;
+  }
   if (adt == FCVSR_F32) hipLaunchKernelGGL((iac_step64_kernel<KDT, FCVSR_F32, ND, FK>), grid, dim3(256), 0, st, a);
   else if (adt == FCVSR_BF16) hipLaunchKernelGGL((iac_step64_kernel<KDT, FCVSR_BF16, ND, FK>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((iac_step64_kernel<KDT, FCVSR_F16, ND, FK>), grid, dim3(256), 0, st, a);

@@ -448,6 +448,461 @@ __global__ __launch_bounds__(512) void irfft_rows_kernel(const float* spec, long
   }
 }
 
+// =====================================================================================================================
+// Two-stage path.  N = R1 * R2 with both factors done as register butterflies (8 ... 20 points each, themselves Ra x Rb
+// Cooley-Tukey products of the 2/3/4/5-point kernels with compile-time twiddles): the FIRST stage reads its inputs straight
+// from HBM, the LAST stage writes its outputs straight to HBM, and the transform crosses LDS exactly once, through ONE
+// complex buffer and one barrier (the multi-stage Stockham path above copies in, ping-pongs between two buffers once per
+// stage and copies out: five LDS round trips and barriers for 180 = 4 x 5 x 9, four for 320 = 8 x 8 x 5).  Half the LDS per
+// line (three 480-thread workgroups per CU for the 180-point columns), a third of the LDS instructions, no per-workgroup f64
+// twiddle generation (a per-length table is built once on the host).  Lengths without such a factorisation, odd channel
+// counts and strided channels stay on the path above.
+template <int R> struct RootTab;
+template <> struct RootTab<8> {
+  static constexpr float c[8] = {1.000000000e+00f, 7.071067812e-01f, 6.123233996e-17f, -7.071067812e-01f, -1.000000000e+00f, -7.071067812e-01f, -1.836970199e-16f, 7.071067812e-01f};
+  static constexpr float s[8] = {0.000000000e+00f, 7.071067812e-01f, 1.000000000e+00f, 7.071067812e-01f, 1.224646799e-16f, -7.071067812e-01f, -1.000000000e+00f, -7.071067812e-01f};
+};
+template <> struct RootTab<9> {
+  static constexpr float c[9] = {1.000000000e+00f, 7.660444431e-01f, 1.736481777e-01f, -5.000000000e-01f, -9.396926208e-01f, -9.396926208e-01f, -5.000000000e-01f, 1.736481777e-01f, 7.660444431e-01f};
+  static constexpr float s[9] = {0.000000000e+00f, 6.427876097e-01f, 9.848077530e-01f, 8.660254038e-01f, 3.420201433e-01f, -3.420201433e-01f, -8.660254038e-01f, -9.848077530e-01f, -6.427876097e-01f};
+};
+template <> struct RootTab<10> {
+  static constexpr float c[10] = {1.000000000e+00f, 8.090169944e-01f, 3.090169944e-01f, -3.090169944e-01f, -8.090169944e-01f, -1.000000000e+00f, -8.090169944e-01f, -3.090169944e-01f, 3.090169944e-01f, 8.090169944e-01f};
+  static constexpr float s[10] = {0.000000000e+00f, 5.877852523e-01f, 9.510565163e-01f, 9.510565163e-01f, 5.877852523e-01f, 1.224646799e-16f, -5.877852523e-01f, -9.510565163e-01f, -9.510565163e-01f, -5.877852523e-01f};
+};
+template <> struct RootTab<12> {
+  static constexpr float c[12] = {1.000000000e+00f, 8.660254038e-01f, 5.000000000e-01f, 6.123233996e-17f, -5.000000000e-01f, -8.660254038e-01f, -1.000000000e+00f, -8.660254038e-01f, -5.000000000e-01f, -1.836970199e-16f, 5.000000000e-01f, 8.660254038e-01f};
+  static constexpr float s[12] = {0.000000000e+00f, 5.000000000e-01f, 8.660254038e-01f, 1.000000000e+00f, 8.660254038e-01f, 5.000000000e-01f, 1.224646799e-16f, -5.000000000e-01f, -8.660254038e-01f, -1.000000000e+00f, -8.660254038e-01f, -5.000000000e-01f};
+};
+template <> struct RootTab<15> {
+  static constexpr float c[15] = {1.000000000e+00f, 9.135454576e-01f, 6.691306064e-01f, 3.090169944e-01f, -1.045284633e-01f, -5.000000000e-01f, -8.090169944e-01f, -9.781476007e-01f, -9.781476007e-01f, -8.090169944e-01f, -5.000000000e-01f, -1.045284633e-01f, 3.090169944e-01f, 6.691306064e-01f, 9.135454576e-01f};
+  static constexpr float s[15] = {0.000000000e+00f, 4.067366431e-01f, 7.431448255e-01f, 9.510565163e-01f, 9.945218954e-01f, 8.660254038e-01f, 5.877852523e-01f, 2.079116908e-01f, -2.079116908e-01f, -5.877852523e-01f, -8.660254038e-01f, -9.945218954e-01f, -9.510565163e-01f, -7.431448255e-01f, -4.067366431e-01f};
+};
+template <> struct RootTab<16> {
+  static constexpr float c[16] = {1.000000000e+00f, 9.238795325e-01f, 7.071067812e-01f, 3.826834324e-01f, 6.123233996e-17f, -3.826834324e-01f, -7.071067812e-01f, -9.238795325e-01f, -1.000000000e+00f, -9.238795325e-01f, -7.071067812e-01f, -3.826834324e-01f, -1.836970199e-16f, 3.826834324e-01f, 7.071067812e-01f, 9.238795325e-01f};
+  static constexpr float s[16] = {0.000000000e+00f, 3.826834324e-01f, 7.071067812e-01f, 9.238795325e-01f, 1.000000000e+00f, 9.238795325e-01f, 7.071067812e-01f, 3.826834324e-01f, 1.224646799e-16f, -3.826834324e-01f, -7.071067812e-01f, -9.238795325e-01f, -1.000000000e+00f, -9.238795325e-01f, -7.071067812e-01f, -3.826834324e-01f};
+};
+template <> struct RootTab<20> {
+  static constexpr float c[20] = {1.000000000e+00f, 9.510565163e-01f, 8.090169944e-01f, 5.877852523e-01f, 3.090169944e-01f, 6.123233996e-17f, -3.090169944e-01f, -5.877852523e-01f, -8.090169944e-01f, -9.510565163e-01f, -1.000000000e+00f, -9.510565163e-01f, -8.090169944e-01f, -5.877852523e-01f, -3.090169944e-01f, -1.836970199e-16f, 3.090169944e-01f, 5.877852523e-01f, 8.090169944e-01f, 9.510565163e-01f};
+  static constexpr float s[20] = {0.000000000e+00f, 3.090169944e-01f, 5.877852523e-01f, 8.090169944e-01f, 9.510565163e-01f, 1.000000000e+00f, 9.510565163e-01f, 8.090169944e-01f, 5.877852523e-01f, 3.090169944e-01f, 1.224646799e-16f, -3.090169944e-01f, -5.877852523e-01f, -8.090169944e-01f, -9.510565163e-01f, -1.000000000e+00f, -9.510565163e-01f, -8.090169944e-01f, -5.877852523e-01f, -3.090169944e-01f};
+};
+
+template <int R, bool INV>
+__device__ __forceinline__ Cx mul_root(Cx a, int m) {           // a * W_R^m (forward W = e^{-2 pi i / R}); m is a constant after unrolling
+  m %= R;
+  if (m == 0) return a;
+  if (4 * m == R) return rot90<INV>(a);
+  if (2 * m == R) return Cx{-a.r, -a.i};
+  if (4 * m == 3 * R) return rot90<!INV>(a);
+  return cmul(a, Cx{RootTab<R>::c[m], INV ? RootTab<R>::s[m] : -RootTab<R>::s[m]});
+}
+
+template <int R, bool INV> struct Dft;                            // in place, natural order in and out
+template <bool INV> struct Dft<2, INV> {
+  static __device__ __forceinline__ void run(Cx* v) { const Cx a = v[0], b = v[1]; v[0] = cadd(a, b); v[1] = csub(a, b); }
+};
+template <bool INV> struct Dft<3, INV> {
+  static __device__ __forceinline__ void run(Cx* v) { dft3<INV>(v[0], v[1], v[2], v[0], v[1], v[2]); }
+};
+template <bool INV> struct Dft<4, INV> {
+  static __device__ __forceinline__ void run(Cx* v) { Cx o[4]; dft4<INV>(v[0], v[1], v[2], v[3], o); v[0] = o[0]; v[1] = o[1]; v[2] = o[2]; v[3] = o[3]; }
+};
+template <bool INV> struct Dft<5, INV> {
+  static __device__ __forceinline__ void run(Cx* v) {
+    const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;
+    const float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
+    const Cx t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+    const Cx u0 = {v[0].r + t1.r + t2.r, v[0].i + t1.i + t2.i};
+    const Cx m1 = {v[0].r + c1 * t1.r + c2 * t2.r, v[0].i + c1 * t1.i + c2 * t2.i};
+    const Cx m2 = {v[0].r + c2 * t1.r + c1 * t2.r, v[0].i + c2 * t1.i + c1 * t2.i};
+    const Cx r1 = rot90<INV>(Cx{s1 * t3.r + s2 * t4.r, s1 * t3.i + s2 * t4.i});
+    const Cx r2 = rot90<INV>(Cx{s2 * t3.r - s1 * t4.r, s2 * t3.i - s1 * t4.i});
+    v[0] = u0; v[1] = cadd(m1, r1); v[4] = csub(m1, r1); v[2] = cadd(m2, r2); v[3] = csub(m2, r2);
+  }
+};
+// R = Ra * Rb:  A[n2][k1] = DFT_Ra over n1 of v[Rb n1 + n2];  A[n2][k1] *= W_R^(n2 k1);  X[k1 + Ra k2] = DFT_Rb over n2
+template <int Ra, int Rb, bool INV>
+__device__ __forceinline__ void dft_ct(Cx* v) {
+  constexpr int R = Ra * Rb;
+  Cx A[Rb][Ra];
+#pragma unroll
+  for (int n2 = 0; n2 < Rb; ++n2) {
+#pragma unroll
+    for (int n1 = 0; n1 < Ra; ++n1) A[n2][n1] = v[Rb * n1 + n2];
+    Dft<Ra, INV>::run(A[n2]);
+#pragma unroll
+    for (int k1 = 1; k1 < Ra; ++k1) A[n2][k1] = mul_root<R, INV>(A[n2][k1], n2 * k1);
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < Ra; ++k1) {
+    Cx t[Rb];
+#pragma unroll
+    for (int n2 = 0; n2 < Rb; ++n2) t[n2] = A[n2][k1];
+    Dft<Rb, INV>::run(t);
+#pragma unroll
+    for (int k2 = 0; k2 < Rb; ++k2) v[k1 + Ra * k2] = t[k2];
+  }
+}
+template <bool INV> struct Dft<8, INV> { static __device__ __forceinline__ void run(Cx* v) { dft_ct<2, 4, INV>(v); } };
+template <bool INV> struct Dft<9, INV> { static __device__ __forceinline__ void run(Cx* v) { dft_ct<3, 3, INV>(v); } };
+template <bool INV> struct Dft<10, INV> { static __device__ __forceinline__ void run(Cx* v) { dft_ct<2, 5, INV>(v); } };
+template <bool INV> struct Dft<12, INV> { static __device__ __forceinline__ void run(Cx* v) { dft_ct<3, 4, INV>(v); } };
+template <bool INV> struct Dft<15, INV> { static __device__ __forceinline__ void run(Cx* v) { dft_ct<3, 5, INV>(v); } };
+template <bool INV> struct Dft<16, INV> { static __device__ __forceinline__ void run(Cx* v) { dft_ct<4, 4, INV>(v); } };
+template <bool INV> struct Dft<20, INV> { static __device__ __forceinline__ void run(Cx* v) { dft_ct<4, 5, INV>(v); } };
+
+// second stage of a lane: inputs y[j + q R1] from LDS times W_N^(q j), DFT_R2 in registers
+template <int R1, int R2, bool INV>
+__device__ __forceinline__ void stage2_load(const float* zr, const float* zi, const float2* tw, int j, int l, int L, Cx* v) {
+#pragma unroll
+  for (int q = 0; q < R2; ++q) {
+    const int idx = (j + q * R1) * L + l;
+    v[q] = Cx{zr[idx], zi[idx]};
+    if (q > 0) {
+      const float2 w = tw[q * j];                      // forward table (cos, -sin); same address across the channel lanes
+      v[q] = cmul(v[q], Cx{w.x, INV ? -w.y : w.y});
+    }
+  }
+  Dft<R2, INV>::run(v);
+}
+
+__device__ __forceinline__ void load_twiddles(float2* tw, const float2* tab, int N) {
+  for (int m = threadIdx.x; m < N; m += blockDim.x) tw[m] = tab[m];
+}
+
+// ---- columns, two stages: lane = (butterfly j, channel l) -------------------------------------------------------------------
+template <int R1, int R2, bool INV>
+__global__ __launch_bounds__(512) void fft_cols2_kernel(const float* in, float* out, long long ps, int im_off, int re_off, int n,
+                                                        int Wf, int logL, const float* mask, const float2* twtab, int nbatch) {
+  constexpr int N = R1 * R2;
+  extern __shared__ __align__(16) float lds[];
+  const int L = 1 << logL;
+  float* zr = lds;
+  float* zi = lds + N * L;
+  float2* tw = reinterpret_cast<float2*>(lds + 2 * N * L);
+  int col, chunk;
+  xcd_line_chunk(&col, &chunk);
+  const int b = col / Wf, kx = col - b * Wf;
+  if (b >= nbatch) return;
+  load_twiddles(tw, twtab, N);
+  const int l = threadIdx.x & (L - 1), j = threadIdx.x >> logL;
+  const int c = chunk * L + l;
+  const bool live = c < n;
+  const long long col0 = ((long long)b * N * Wf + kx) * ps + c;
+  const long long rstride = (long long)Wf * ps;
+  if (j < R2) {
+    Cx v[R1];
+#pragma unroll
+    for (int q = 0; q < R1; ++q) {
+      const int y = j + q * R2;
+      const float* px = in + col0 + (long long)y * rstride;
+      const float m = mask ? mask[y * Wf + kx] : 1.f;
+      v[q] = live ? Cx{px[re_off] * m, px[im_off] * m} : Cx{0.f, 0.f};
+    }
+    Dft<R1, INV>::run(v);
+#pragma unroll
+    for (int p = 0; p < R1; ++p) {
+      const int idx = (j * R1 + p) * L + l;
+      zr[idx] = v[p].r;
+      zi[idx] = v[p].i;
+    }
+  }
+  __syncthreads();
+  if (j < R1) {
+    Cx v[R2];
+    stage2_load<R1, R2, INV>(zr, zi, tw, j, l, L, v);
+    if (live) {
+#pragma unroll
+      for (int p = 0; p < R2; ++p) {
+        float* px = out + col0 + (long long)(j + p * R1) * rstride;
+        px[re_off] = v[p].r;
+        px[im_off] = v[p].i;
+      }
+    }
+  }
+}
+
+// a pair of adjacent channels of one pixel (the real / imaginary part of a two-for-one lane)
+__device__ __forceinline__ Cx ld_pair(const float* base, long long idx, int dt) {
+  if (dt == FCVSR_F32) { const float2 v = *reinterpret_cast<const float2*>(base + idx); return Cx{v.x, v.y}; }
+  const unsigned v = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(base) + idx);
+  if (dt == FCVSR_BF16) return Cx{__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  const h2 h = __builtin_bit_cast(h2, v);
+  return Cx{(float)h[0], (float)h[1]};
+}
+
+// ---- forward rows, two stages + untangle: complex lane l carries channels c0 + 2l (real part) and c0 + 2l + 1 (imaginary) ----
+template <int R1, int R2>
+__global__ __launch_bounds__(512, 4) void rfft_rows2_kernel(View src, int src_dt, int n, int H, int logL, float* spec, long long ps,
+                                                         int im_off, int re_off, const float2* twtab, int nbatch, int nlines) {
+  constexpr int N = R1 * R2, Wf = N / 2 + 1;
+  extern __shared__ __align__(16) float lds[];
+  const int L = 1 << logL;
+  float* zr = lds;
+  float* zi = lds + N * L;
+  float2* tw = reinterpret_cast<float2*>(lds + 2 * N * L);
+  int grp, chunk;
+  xcd_line_chunk(&grp, &chunk);
+  const int row0 = grp * nlines, nrows = nbatch * H;
+  if (row0 >= nrows) return;
+  load_twiddles(tw, twtab, N);
+  const int l = threadIdx.x & (L - 1), j = threadIdx.x >> logL;
+  const int ca = chunk * 2 * L + 2 * l;
+  const bool live = ca < n && j < R2;                             // n is even on this path
+  // addresses = wave-uniform 64-bit base (line, chunk, q) + one 32-bit lane offset (host checks W * sx < 2^31)
+  const int lane_off = j * (int)src.sx + 2 * l;
+  auto issue = [&](const int row, Cx* v) {
+    const int b = row / H, y = row - b * H;
+    const long long sp = (long long)b * src.sb + (long long)y * src.sy + chunk * 2 * L;
+#pragma unroll
+    for (int q = 0; q < R1; ++q) {
+      const float* bq = src_dt == FCVSR_F32 ? src.p + (sp + (long long)q * R2 * src.sx)
+                                            : reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(src.p) + (sp + (long long)q * R2 * src.sx));
+      v[q] = live ? ld_pair(bq, lane_off, src_dt) : Cx{0.f, 0.f};
+    }
+  };
+  {
+    const int row = row0;
+    if (j < R2) {
+      Cx v[R1];
+      issue(row, v);
+      Dft<R1, false>::run(v);
+#pragma unroll
+      for (int p = 0; p < R1; ++p) {
+        const int idx = (j * R1 + p) * L + l;
+        zr[idx] = v[p].r;
+        zi[idx] = v[p].i;
+      }
+    }
+    __syncthreads();
+    if (j < R1) {                                                  // in place: a lane writes exactly the positions it read
+      Cx w[R2];
+      stage2_load<R1, R2, false>(zr, zi, tw, j, l, L, w);
+#pragma unroll
+      for (int p = 0; p < R2; ++p) {
+        const int idx = (j + p * R1) * L + l;
+        zr[idx] = w[p].r;
+        zi[idx] = w[p].i;
+      }
+    }
+    __syncthreads();
+    // Z = FFT(xa + i xb):  Xa[k] = (Z[k] + conj Z[N-k]) / 2,  Xb[k] = (Z[k] - conj Z[N-k]) / (2i)
+    float* op = spec + ((long long)row * Wf) * ps;
+    for (int t = threadIdx.x; t < Wf * L; t += blockDim.x) {
+      const int l2 = t & (L - 1), k = t >> logL;
+      const int kn = k ? N - k : 0;
+      const int c2 = chunk * 2 * L + 2 * l2;
+      if (c2 < n) {
+        const float kr = zr[k * L + l2], ki = zi[k * L + l2], nr = zr[kn * L + l2], ni = zi[kn * L + l2];
+        float* o = op + (long long)k * ps + c2;
+        *reinterpret_cast<float2*>(o + re_off) = make_float2(0.5f * (kr + nr), 0.5f * (ki + ni));
+        *reinterpret_cast<float2*>(o + im_off) = make_float2(0.5f * (ki - ni), 0.5f * (nr - kr));
+      }
+    }
+  }
+}
+
+// ---- inverse rows, two stages: Hermitian extension and two-for-one packing on load, real pairs stored from registers --------
+template <int R1, int R2>
+__global__ __launch_bounds__(512, 4) void irfft_rows2_kernel(const float* spec, long long ps, int im_off, int re_off, int n, int H,
+                                                          int logL, View dst, float scale, const float2* twtab, int nbatch,
+                                                          int nlines) {
+  constexpr int N = R1 * R2, Wf = N / 2 + 1;
+  extern __shared__ __align__(16) float lds[];
+  const int L = 1 << logL;
+  float* zr = lds;
+  float* zi = lds + N * L;
+  float2* tw = reinterpret_cast<float2*>(lds + 2 * N * L);
+  int grp, chunk;
+  xcd_line_chunk(&grp, &chunk);
+  const int row0 = grp * nlines, nrows = nbatch * H;
+  if (row0 >= nrows) return;
+  load_twiddles(tw, twtab, N);
+  const int l = threadIdx.x & (L - 1), j = threadIdx.x >> logL;
+  const int ca = chunk * 2 * L + 2 * l;
+  const bool live = ca < n;
+  auto issue = [&](const int row, Cx* v) {                         // Hermitian extension + two-for-one packing: Z = Xa + i Xb
+    const float* ip = spec + ((long long)row * Wf) * ps + chunk * 2 * L;      // wave-uniform; lane part below is 32-bit
+#pragma unroll
+    for (int q = 0; q < R1; ++q) {
+      const int k = j + q * R2;
+      const int kk = (k <= N / 2) ? k : N - k;
+      const float sgn = (k > N / 2) ? -1.f : 1.f;
+      const float keep = ((kk == 0) || ((N % 2 == 0) && kk == N / 2)) ? 0.f : sgn;   // imag parts: dropped at DC / Nyquist
+      if (live && j < R2) {
+        const int lo = kk * (int)ps + 2 * l;
+        const float2 re = *reinterpret_cast<const float2*>(ip + re_off + lo);   // (Re Xa, Re Xb)
+        const float2 im = *reinterpret_cast<const float2*>(ip + im_off + lo);   // (Im Xa, Im Xb)
+        v[q] = Cx{re.x - keep * im.y, keep * im.x + re.y};
+      } else {
+        v[q] = Cx{0.f, 0.f};
+      }
+    }
+  };
+  {
+    const int row = row0;
+    if (j < R2) {
+      Cx v[R1];
+      issue(row, v);
+      Dft<R1, true>::run(v);
+#pragma unroll
+      for (int p = 0; p < R1; ++p) {
+        const int idx = (j * R1 + p) * L + l;
+        zr[idx] = v[p].r;
+        zi[idx] = v[p].i;
+      }
+    }
+    __syncthreads();
+    if (j < R1) {
+      Cx w[R2];
+      stage2_load<R1, R2, true>(zr, zi, tw, j, l, L, w);
+      if (live) {
+        const int b = row / H, y = row - b * H;
+        float* op = dst.p + (long long)b * dst.sb + (long long)y * dst.sy + chunk * 2 * L;
+        const int lo = j * (int)dst.sx + 2 * l;
+#pragma unroll
+        for (int p = 0; p < R2; ++p)
+          *reinterpret_cast<float2*>(op + (long long)p * R1 * dst.sx + lo) = make_float2(w[p].r * scale, w[p].i * scale);
+      }
+    }
+  }
+}
+
+// Factorisations of the two-stage path (first factor = first stage).  Listed lengths only; everything else uses the plan.
+struct TwoStage { int N, R1, R2; };
+static const TwoStage kTwoStage[] = {{64, 8, 8},    {72, 8, 9},    {80, 8, 10},   {96, 8, 12},   {128, 8, 16},  {144, 12, 12},
+                                     {160, 10, 16}, {180, 12, 15}, {192, 12, 16}, {240, 15, 16}, {256, 16, 16}, {320, 16, 20}};
+static const TwoStage* two_stage(int N) {
+  static const bool off = getenv("FCVSR_FFT_2S") && atoi(getenv("FCVSR_FFT_2S")) == 0;
+  if (off) return nullptr;
+  for (const TwoStage& t : kTwoStage)
+    if (t.N == N) return &t;
+  return nullptr;
+}
+
+// per-device table of W_N^m = (cos, -sin)(2 pi m / N), f64 on the host, rounded once (like pocketfft's table)
+static const float2* twiddle_table(int N, hipStream_t st) {
+  struct Entry { int N; float2* p; };
+  static Entry tabs[64][16];
+  static int ntab[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { set_error("fft: bad device index"); return nullptr; }
+  for (int i = 0; i < ntab[dev]; ++i)
+    if (tabs[dev][i].N == N) return tabs[dev][i].p;
+  if (ntab[dev] >= 16) { set_error("fft: too many twiddle tables"); return nullptr; }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+    set_error("fft: first transform of length %d on this device inside a stream capture (run it once eagerly first)", N);
+    return nullptr;
+  }
+  float2* host = (float2*)malloc(sizeof(float2) * N);
+  if (!host) { set_error("fft: out of host memory"); return nullptr; }
+  for (int m = 0; m < N; ++m) {
+    const double a = 2.0 * 3.14159265358979323846 * (double)m / (double)N;
+    host[m] = make_float2((float)cos(a), (float)(-sin(a)));
+  }
+  float2* d = nullptr;
+  hipError_t e = hipMalloc(&d, sizeof(float2) * N);
+  if (e == hipSuccess) e = hipMemcpy(d, host, sizeof(float2) * N, hipMemcpyHostToDevice);
+  free(host);
+  if (e != hipSuccess) { set_error("fft: twiddle table: %s", hipGetErrorString(e)); return nullptr; }
+  tabs[dev][ntab[dev]].N = N;
+  tabs[dev][ntab[dev]].p = d;
+  ++ntab[dev];
+  return d;
+}
+
+// lanes per workgroup of the two-stage kernels: a power of two with max(R1, R2) * L <= 512 threads and one complex buffer
+// (8 N L bytes) within ~48 KB, so that three workgroups share a CU
+static int pick_lanes2(const TwoStage& ts, int lanes_needed) {
+  const int rmax = ts.R1 > ts.R2 ? ts.R1 : ts.R2;
+  int L = 32;
+  while (L > 1 && (rmax * L > 512 || 8ll * ts.N * L > 48 * 1024)) L >>= 1;
+  while (L > 1 && L / 2 >= lanes_needed) L >>= 1;
+  return L;
+}
+static int ilog2(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
+
+#define FCVSR_FFT2_DISPATCH(ts, CALL)                                                                        \
+  do {                                                                                                       \
+    switch ((ts).N) {                                                                                        \
+      case 64: CALL(8, 8); break;     case 72: CALL(8, 9); break;     case 80: CALL(8, 10); break;           \
+      case 96: CALL(8, 12); break;    case 128: CALL(8, 16); break;   case 144: CALL(12, 12); break;         \
+      case 160: CALL(10, 16); break;  case 180: CALL(12, 15); break;  case 192: CALL(12, 16); break;         \
+      case 240: CALL(15, 16); break;  case 256: CALL(16, 16); break;  case 320: CALL(16, 20); break;         \
+    }                                                                                                        \
+  } while (0)
+
+static int launch_cols2(const TwoStage& ts, const float* in, float* out, long long ps, int im_off, int re_off, int n, int Wf,
+                        int B, bool inverse, const float* mask, hipStream_t st) {
+  const float2* tw = twiddle_table(ts.N, st);
+  if (!tw) return FCVSR_E_ARG;
+  const int L = pick_lanes2(ts, n), logL = ilog2(L);
+  const int rmax = ts.R1 > ts.R2 ? ts.R1 : ts.R2;
+  const dim3 grid(cdiv(n, L), (B * Wf + 7) / 8 * 8), block((rmax * L + 63) / 64 * 64);
+  const size_t lds = 8ull * ts.N * L + 8ull * ts.N;
+#define FCVSR_COLS2(A_, B_)                                                                                                 \
+  if (inverse) hipLaunchKernelGGL((fft_cols2_kernel<A_, B_, true>), grid, block, lds, st, in, out, ps, im_off, re_off, n,   \
+                                  Wf, logL, mask, tw, B);                                                                    \
+  else hipLaunchKernelGGL((fft_cols2_kernel<A_, B_, false>), grid, block, lds, st, in, out, ps, im_off, re_off, n, Wf,      \
+                          logL, mask, tw, B)
+  FCVSR_FFT2_DISPATCH(ts, FCVSR_COLS2);
+#undef FCVSR_COLS2
+  return 0;
+}
+
+// consecutive lines per workgroup of the pipelined row kernels (FCVSR_FFT_NL overrides)
+static int rows_per_wg(int nrows) {
+  static const int env = getenv("FCVSR_FFT_NL") ? atoi(getenv("FCVSR_FFT_NL")) : 0;
+  (void)env; (void)nrows;
+  return 1;                                                        // one line per workgroup (see the note at rfft_rows2_kernel)
+}
+
+static int launch_rfft_rows2(const TwoStage& ts, const fcvsr_view* src, int n, int B, int H, float* spec, long long ps, int im_off,
+                             int re_off, hipStream_t st) {
+  const float2* tw = twiddle_table(ts.N, st);
+  if (!tw) return FCVSR_E_ARG;
+  static const int envL = getenv("FCVSR_FFT_ROWL") ? atoi(getenv("FCVSR_FFT_ROWL")) : 0;
+  int L = pick_lanes2(ts, n / 2);
+  if (envL > 0 && envL < L) L = envL;
+  const int logL = ilog2(L);
+  const int rmax = ts.R1 > ts.R2 ? ts.R1 : ts.R2;
+  const int nl = rows_per_wg(B * H);
+  const dim3 grid(cdiv(n, 2 * L), (cdiv(B * H, nl) + 7) / 8 * 8), block((rmax * L + 63) / 64 * 64);
+  const size_t lds = 8ull * ts.N * L + 8ull * ts.N;
+#define FCVSR_ROWS2(A_, B_) \
+  hipLaunchKernelGGL((rfft_rows2_kernel<A_, B_>), grid, block, lds, st, to_view(*src), (int)src->dtype, n, H, logL, spec, ps, im_off, re_off, tw, B, nl)
+  FCVSR_FFT2_DISPATCH(ts, FCVSR_ROWS2);
+#undef FCVSR_ROWS2
+  return 0;
+}
+
+static int launch_irfft_rows2(const TwoStage& ts, const float* spec, long long ps, int im_off, int re_off, int n, int B, int H,
+                              const fcvsr_view* dst, float scale, hipStream_t st) {
+  const float2* tw = twiddle_table(ts.N, st);
+  if (!tw) return FCVSR_E_ARG;
+  static const int envL = getenv("FCVSR_FFT_ROWL") ? atoi(getenv("FCVSR_FFT_ROWL")) : 0;
+  int L = pick_lanes2(ts, n / 2);
+  if (envL > 0 && envL < L) L = envL;
+  const int logL = ilog2(L);
+  const int rmax = ts.R1 > ts.R2 ? ts.R1 : ts.R2;
+  const int nl = rows_per_wg(B * H);
+  const dim3 grid(cdiv(n, 2 * L), (cdiv(B * H, nl) + 7) / 8 * 8), block((rmax * L + 63) / 64 * 64);
+  const size_t lds = 8ull * ts.N * L + 8ull * ts.N;
+#define FCVSR_IROWS2(A_, B_) \
+  hipLaunchKernelGGL((irfft_rows2_kernel<A_, B_>), grid, block, lds, st, spec, ps, im_off, re_off, n, H, logL, to_view(*dst), scale, tw, B, nl)
+  FCVSR_FFT2_DISPATCH(ts, FCVSR_IROWS2);
+#undef FCVSR_IROWS2
+  return 0;
+}
+
+// channel pairs of a view are loaded / stored as one 4-byte (16-bit) or 8-byte (f32) access
+static bool pair_ok(const fcvsr_view* v) {
+  const int al = v->dtype == FCVSR_F32 ? 8 : 4;
+  return v->sc == 1 && v->sx % 2 == 0 && v->sy % 2 == 0 && v->sb % 2 == 0 && ((uintptr_t)v->ptr % al) == 0;
+}
+
 static long long lds_budget() {
   static long long b = -1;
   if (b < 0) {
@@ -484,7 +939,14 @@ extern "C" int fcvsr_rfft2(const fcvsr_view* src, int B, int H, int W, int n, fl
   const int Wf = W / 2 + 1;
   hipStream_t st = (hipStream_t)stream;
   const bool spec_ok = pix_stride % 4 == 0 && im_off % 4 == 0 && re_off % 4 == 0 && ((uintptr_t)spec % 16) == 0;
-  {
+  const bool spec_pair = pix_stride % 2 == 0 && im_off % 2 == 0 && re_off % 2 == 0 && ((uintptr_t)spec % 8) == 0;
+  const TwoStage* tsw = two_stage(W);
+  const TwoStage* tsh = two_stage(H);
+  if (tsw && n % 2 == 0 && pair_ok(src) && spec_pair) {
+    const int rc = launch_rfft_rows2(*tsw, src, n, B, H, spec, (long long)pix_stride, im_off, re_off, st);
+    if (rc) return rc;
+    FCVSR_LAUNCH_CHECK();
+  } else {
     const int L = pick_lanes(W, (n + 1) / 2);
     FCVSR_CHECK_ARG(16ll * W * L + 8ll * W <= 160 * 1024, "row too long for LDS");
     const size_t lds = 16ull * W * L + 8ull * W;
@@ -497,7 +959,11 @@ extern "C" int fcvsr_rfft2(const fcvsr_view* src, int B, int H, int W, int n, fl
                        (long long)pix_stride, im_off, re_off, pw, vec, B);
     FCVSR_LAUNCH_CHECK();
   }
-  {
+  if (tsh) {
+    const int rc = launch_cols2(*tsh, spec, spec, (long long)pix_stride, im_off, re_off, n, Wf, B, false, nullptr, st);
+    if (rc) return rc;
+    FCVSR_LAUNCH_CHECK();
+  } else {
     const int L = pick_lanes(H, n);
     FCVSR_CHECK_ARG(16ll * H * L + 8ll * H <= 160 * 1024, "column too long for LDS");
     const size_t lds = 16ull * H * L + 8ull * H;
@@ -522,7 +988,14 @@ extern "C" int fcvsr_irfft2(const float* spec, int64_t pix_stride, int im_off, i
   hipStream_t st = (hipStream_t)stream;
   float* mid = work ? work : const_cast<float*>(spec);
   const bool spec_ok = pix_stride % 4 == 0 && im_off % 4 == 0 && re_off % 4 == 0 && ((uintptr_t)spec % 16) == 0;
-  {
+  const bool mid_pair = pix_stride % 2 == 0 && im_off % 2 == 0 && re_off % 2 == 0 && ((uintptr_t)mid % 8) == 0;
+  const TwoStage* tsw = two_stage(W);
+  const TwoStage* tsh = two_stage(H);
+  if (tsh) {
+    const int rc = launch_cols2(*tsh, spec, mid, (long long)pix_stride, im_off, re_off, n, Wf, B, true, mask, st);
+    if (rc) return rc;
+    FCVSR_LAUNCH_CHECK();
+  } else {
     const int L = pick_lanes(H, n);
     FCVSR_CHECK_ARG(16ll * H * L + 8ll * H <= 160 * 1024, "column too long for LDS");
     const size_t lds = 16ull * H * L + 8ull * H;
@@ -533,7 +1006,12 @@ extern "C" int fcvsr_irfft2(const float* spec, int64_t pix_stride, int im_off, i
                        Wf, L, 1, mask, ph, vec, B);
     FCVSR_LAUNCH_CHECK();
   }
-  {
+  if (tsw && n % 2 == 0 && pair_ok(dst) && mid_pair) {
+    const int rc = launch_irfft_rows2(*tsw, mid, (long long)pix_stride, im_off, re_off, n, B, H, dst,
+                                      1.0f / ((float)H * (float)W), st);
+    if (rc) return rc;
+    FCVSR_LAUNCH_CHECK();
+  } else {
     const int L = pick_lanes(W, (n + 1) / 2);
     FCVSR_CHECK_ARG(16ll * W * L + 8ll * W <= 160 * 1024, "row too long for LDS");
     const size_t lds = 16ull * W * L + 8ull * W;

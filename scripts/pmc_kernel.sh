@@ -1,15 +1,14 @@
 #!/bin/bash
 # Counter passes over one micro-benchmark, summarised for the kernels whose name contains $1.
 #   scripts/pmc_kernel.sh <name-substring> <out-tag> <script.py> [ENV=VAL ...]
-# rocprofv3 --pmc only (never combined with the sys / runtime traces); one pass per counter group.
+# rocprofv3 --pmc only (never combined with the sys / runtime traces); one pass per counter group (SQ groups only: the TCC / TCP
+# groups did not finish within 5 minutes on this pool).
 F=$1; TAG=$2; S=$3; shift 3
 R=$(pwd); mkdir -p $R/gpurun_out/$TAG; cd /tmp && export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_WAVES" \
-           "SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS" \
-           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
-           "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum"; do
+           "SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS"; do
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_$TAG/g$i -o g -- python3 $R/$S > $R/gpurun_out/$TAG/run$i.log 2>&1 || echo "group $i failed"
 done

@@ -623,19 +623,22 @@ __global__ __launch_bounds__(512) void fft_cols2_kernel(const float* in, float* 
 }
 
 // a pair of adjacent channels of one pixel (the real / imaginary part of a two-for-one lane)
-__device__ __forceinline__ Cx ld_pair(const float* base, long long idx, int dt) {
-  if (dt == FCVSR_F32) { const float2 v = *reinterpret_cast<const float2*>(base + idx); return Cx{v.x, v.y}; }
+template <int DT>
+__device__ __forceinline__ Cx ld_pair(const float* base, long long idx) {
+  if (DT == FCVSR_F32) { const float2 v = *reinterpret_cast<const float2*>(base + idx); return Cx{v.x, v.y}; }
   const unsigned v = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(base) + idx);
-  if (dt == FCVSR_BF16) return Cx{__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
+  if (DT == FCVSR_BF16) return Cx{__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
   typedef __attribute__((ext_vector_type(2))) _Float16 h2;
   const h2 h = __builtin_bit_cast(h2, v);
   return Cx{(float)h[0], (float)h[1]};
 }
 
 // ---- forward rows, two stages + untangle: complex lane l carries channels c0 + 2l (real part) and c0 + 2l + 1 (imaginary) ----
-template <int R1, int R2>
-__global__ __launch_bounds__(512, 4) void rfft_rows2_kernel(View src, int src_dt, int n, int H, int logL, float* spec, long long ps,
-                                                         int im_off, int re_off, const float2* twtab, int nbatch, int nlines) {
+// The source dtype is a template parameter: with a run-time switch every load sat in its own branch and the 16 loads of a
+// lane were issued one round trip after the other (131 us of a 170 us pass was load wait).
+template <int R1, int R2, int SDT>
+__global__ __launch_bounds__(512, 4) void rfft_rows2_kernel(View src, int n, int H, int logL, float* spec, long long ps,
+                                                         int im_off, int re_off, const float2* twtab, int nbatch) {
   constexpr int N = R1 * R2, Wf = N / 2 + 1;
   extern __shared__ __align__(16) float lds[];
   const int L = 1 << logL;
@@ -644,7 +647,7 @@ __global__ __launch_bounds__(512, 4) void rfft_rows2_kernel(View src, int src_dt
   float2* tw = reinterpret_cast<float2*>(lds + 2 * N * L);
   int grp, chunk;
   xcd_line_chunk(&grp, &chunk);
-  const int row0 = grp * nlines, nrows = nbatch * H;
+  const int row0 = grp, nrows = nbatch * H;
   if (row0 >= nrows) return;
   load_twiddles(tw, twtab, N);
   const int l = threadIdx.x & (L - 1), j = threadIdx.x >> logL;
@@ -657,9 +660,9 @@ __global__ __launch_bounds__(512, 4) void rfft_rows2_kernel(View src, int src_dt
     const long long sp = (long long)b * src.sb + (long long)y * src.sy + chunk * 2 * L;
 #pragma unroll
     for (int q = 0; q < R1; ++q) {
-      const float* bq = src_dt == FCVSR_F32 ? src.p + (sp + (long long)q * R2 * src.sx)
-                                            : reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(src.p) + (sp + (long long)q * R2 * src.sx));
-      v[q] = live ? ld_pair(bq, lane_off, src_dt) : Cx{0.f, 0.f};
+      const float* bq = SDT == FCVSR_F32 ? src.p + (sp + (long long)q * R2 * src.sx)
+                                         : reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(src.p) + (sp + (long long)q * R2 * src.sx));
+      v[q] = live ? ld_pair<SDT>(bq, lane_off) : Cx{0.f, 0.f};
     }
   };
   {
@@ -706,8 +709,7 @@ __global__ __launch_bounds__(512, 4) void rfft_rows2_kernel(View src, int src_dt
 // ---- inverse rows, two stages: Hermitian extension and two-for-one packing on load, real pairs stored from registers --------
 template <int R1, int R2>
 __global__ __launch_bounds__(512, 4) void irfft_rows2_kernel(const float* spec, long long ps, int im_off, int re_off, int n, int H,
-                                                          int logL, View dst, float scale, const float2* twtab, int nbatch,
-                                                          int nlines) {
+                                                          int logL, View dst, float scale, const float2* twtab, int nbatch) {
   constexpr int N = R1 * R2, Wf = N / 2 + 1;
   extern __shared__ __align__(16) float lds[];
   const int L = 1 << logL;
@@ -716,7 +718,7 @@ __global__ __launch_bounds__(512, 4) void irfft_rows2_kernel(const float* spec, 
   float2* tw = reinterpret_cast<float2*>(lds + 2 * N * L);
   int grp, chunk;
   xcd_line_chunk(&grp, &chunk);
-  const int row0 = grp * nlines, nrows = nbatch * H;
+  const int row0 = grp, nrows = nbatch * H;
   if (row0 >= nrows) return;
   load_twiddles(tw, twtab, N);
   const int l = threadIdx.x & (L - 1), j = threadIdx.x >> logL;
@@ -852,13 +854,6 @@ static int launch_cols2(const TwoStage& ts, const float* in, float* out, long lo
   return 0;
 }
 
-// consecutive lines per workgroup of the pipelined row kernels (FCVSR_FFT_NL overrides)
-static int rows_per_wg(int nrows) {
-  static const int env = getenv("FCVSR_FFT_NL") ? atoi(getenv("FCVSR_FFT_NL")) : 0;
-  (void)env; (void)nrows;
-  return 1;                                                        // one line per workgroup (see the note at rfft_rows2_kernel)
-}
-
 static int launch_rfft_rows2(const TwoStage& ts, const fcvsr_view* src, int n, int B, int H, float* spec, long long ps, int im_off,
                              int re_off, hipStream_t st) {
   const float2* tw = twiddle_table(ts.N, st);
@@ -868,11 +863,18 @@ static int launch_rfft_rows2(const TwoStage& ts, const fcvsr_view* src, int n, i
   if (envL > 0 && envL < L) L = envL;
   const int logL = ilog2(L);
   const int rmax = ts.R1 > ts.R2 ? ts.R1 : ts.R2;
-  const int nl = rows_per_wg(B * H);
-  const dim3 grid(cdiv(n, 2 * L), (cdiv(B * H, nl) + 7) / 8 * 8), block((rmax * L + 63) / 64 * 64);
+  const dim3 grid(cdiv(n, 2 * L), (B * H + 7) / 8 * 8), block((rmax * L + 63) / 64 * 64);
   const size_t lds = 8ull * ts.N * L + 8ull * ts.N;
-#define FCVSR_ROWS2(A_, B_) \
-  hipLaunchKernelGGL((rfft_rows2_kernel<A_, B_>), grid, block, lds, st, to_view(*src), (int)src->dtype, n, H, logL, spec, ps, im_off, re_off, tw, B, nl)
+#define FCVSR_ROWS2(A_, B_)                                                                                                      \
+  if (src->dtype == FCVSR_F32)                                                                                                   \
+    hipLaunchKernelGGL((rfft_rows2_kernel<A_, B_, FCVSR_F32>), grid, block, lds, st, to_view(*src), n, H, logL, spec, ps, im_off, \
+                       re_off, tw, B);                                                                                           \
+  else if (src->dtype == FCVSR_BF16)                                                                                             \
+    hipLaunchKernelGGL((rfft_rows2_kernel<A_, B_, FCVSR_BF16>), grid, block, lds, st, to_view(*src), n, H, logL, spec, ps,       \
+                       im_off, re_off, tw, B);                                                                                   \
+  else                                                                                                                           \
+    hipLaunchKernelGGL((rfft_rows2_kernel<A_, B_, FCVSR_F16>), grid, block, lds, st, to_view(*src), n, H, logL, spec, ps, im_off, \
+                       re_off, tw, B)
   FCVSR_FFT2_DISPATCH(ts, FCVSR_ROWS2);
 #undef FCVSR_ROWS2
   return 0;
@@ -887,11 +889,10 @@ static int launch_irfft_rows2(const TwoStage& ts, const float* spec, long long p
   if (envL > 0 && envL < L) L = envL;
   const int logL = ilog2(L);
   const int rmax = ts.R1 > ts.R2 ? ts.R1 : ts.R2;
-  const int nl = rows_per_wg(B * H);
-  const dim3 grid(cdiv(n, 2 * L), (cdiv(B * H, nl) + 7) / 8 * 8), block((rmax * L + 63) / 64 * 64);
+  const dim3 grid(cdiv(n, 2 * L), (B * H + 7) / 8 * 8), block((rmax * L + 63) / 64 * 64);
   const size_t lds = 8ull * ts.N * L + 8ull * ts.N;
 #define FCVSR_IROWS2(A_, B_) \
-  hipLaunchKernelGGL((irfft_rows2_kernel<A_, B_>), grid, block, lds, st, spec, ps, im_off, re_off, n, H, logL, to_view(*dst), scale, tw, B, nl)
+  hipLaunchKernelGGL((irfft_rows2_kernel<A_, B_>), grid, block, lds, st, spec, ps, im_off, re_off, n, H, logL, to_view(*dst), scale, tw, B)
   FCVSR_FFT2_DISPATCH(ts, FCVSR_IROWS2);
 #undef FCVSR_IROWS2
   return 0;

@@ -279,12 +279,14 @@ class Engine:
         st = stream_ptr()
         par = self._par
 
-        spec = self._new(dev, B, H, Wf, 6 * n)                   # [x1f | x2f | x3f], each [imag(n), real(n)]
+        # three spectra, each [imag(n), real(n)] per pixel.  Separate tensors, not one 6n-channel record: the FFT passes
+        # then write whole 512-byte pixel records (two channel chunks side by side) instead of a third of a 1536-byte one
+        spec = self._new(dev, 3, B, H, Wf, 2 * n)
+        fs = 2 * n                                               # pixel stride of a spectrum, in floats
         for i, xi in enumerate((x1, x2, x3)):
             v = view(xi)
-            check(L.fcvsr_rfft2(C.byref(v), B, H, W, n, spec[..., 2 * n * i:].data_ptr(), 6 * n, 0, n, st),
-                  "fcvsr_rfft2")
-        x1f, x2f, x3f = spec[..., :2 * n], spec[..., 2 * n:4 * n], spec[..., 4 * n:]
+            check(L.fcvsr_rfft2(C.byref(v), B, H, W, n, spec[i].data_ptr(), fs, 0, n, st), "fcvsr_rfft2")
+        x1f, x2f, x3f = spec[0], spec[1], spec[2]
 
         # offset spectra: (x?f - x2f) + convfuse(cat[x?f, x2f]); batch index = dir*B + b
         fdt = self._adt(freq=True)
@@ -295,7 +297,7 @@ class Engine:
             # the whole convfuse stack for both directions in one kernel: hidden tensors never leave the CU
             ws = [self._weights(f"MGAA.convfuse.{i}", torch.bfloat16)[0] for i in (0, 2, 4)]
             P2 = C.c_void_p * 2
-            check(L.fcvsr_freq_mlp3(P2(x1f.data_ptr(), x3f.data_ptr()), P2(x2f.data_ptr(), x2f.data_ptr()), 2, 6 * n,
+            check(L.fcvsr_freq_mlp3(P2(x1f.data_ptr(), x3f.data_ptr()), P2(x2f.data_ptr(), x2f.data_ptr()), 2, fs,
                                     B * H * Wf, ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(),
                                     P2(off[:B].data_ptr(), off[B:].data_ptr()), 2 * n, st), "fcvsr_freq_mlp3")
         else:
@@ -313,7 +315,7 @@ class Engine:
         fuse_head = fuse_mlp and getattr(m, "fuse_freq_head", True)
         if fuse_head:
             # convcrt (128 -> 64 -> 4 on the centre spectrum) as one launch
-            check(L.fcvsr_freq_head(x2f.data_ptr(), hip.F32, 6 * n, B * H * Wf,
+            check(L.fcvsr_freq_head(x2f.data_ptr(), hip.F32, fs, B * H * Wf,
                                     self._weights("MGAA.convcrt.0", torch.bfloat16)[0].data_ptr(), None,
                                     self._weights("MGAA.convcrt.2", torch.bfloat16)[0].data_ptr(), sim.data_ptr(), st),
                   "fcvsr_freq_head(convcrt)")
@@ -327,7 +329,7 @@ class Engine:
             c1 = self._new(dev, 2 * B, H, Wf, n, dtype=fdt)
             corr = self._new(dev, B, H, Wf, 84)                  # 81 live channels + 3 zero pad (16-byte pixels)
             cv = view(corr)
-            check(L.fcvsr_corr_lookup(x1f.data_ptr(), x2f.data_ptr(), 6 * n, B, H, Wf, 2 * n, 4, Wf, C.byref(cv), st),
+            check(L.fcvsr_corr_lookup(x1f.data_ptr(), x2f.data_ptr(), fs, B, H, Wf, 2 * n, 4, Wf, C.byref(cv), st),
                   "fcvsr_corr_lookup")
             for d in range(2):
                 self._conv("MGAA.convcorr.0", [off[d * B:(d + 1) * B], corr], c0[d * B:(d + 1) * B], act=ACT_RELU, freq=True)
@@ -351,7 +353,7 @@ class Engine:
             xs = min(Wf, 8)
             corr = self._new(dev, B, H, xs, 84)
             cv = view(corr)
-            check(L.fcvsr_corr_lookup(x1f.data_ptr(), x2f.data_ptr(), 6 * n, B, H, Wf, 2 * n, 4, xs, C.byref(cv), st),
+            check(L.fcvsr_corr_lookup(x1f.data_ptr(), x2f.data_ptr(), fs, B, H, Wf, 2 * n, 4, xs, C.byref(cv), st),
                   "fcvsr_corr_lookup")
             off_s = off[:, :, :xs].to(torch.float32, memory_format=torch.contiguous_format)   # (2B,H,xs,2n) strip copy
             c0_s = self._new(dev, 2 * B, H, xs, n, dtype=fdt)

@@ -10,6 +10,7 @@
 //      the 340 halo pixels - 44 small MFMAs instead of 576 multiply-adds per output pixel on the vector ALU.
 //   3. out[y][x] += bias + sum_tap P[y+dy][x+dx][tap]   (out holds the bilinear x4 base skip).
 // HBM traffic per output pixel: 14 bytes of u1 (with halo) + 8 bytes of out, instead of 128 written + ~170 read.
+#include <stdlib.h>
 #include "common.h"
 #include "mfma_util.h"
 
@@ -35,6 +36,7 @@ struct TailArgs {
   const float* bl;         // conv_last0 bias (1 value, may be null)
   View out;                // (B, 2*H2, 2*W2, 1) f32, read-modify-write
   int B, H2, W2, tiles_x, tiles_y;
+  int ntiles;              // B * tiles_x * tiles_y, split into contiguous runs over the launched workgroups
 };
 
 template <bool BF16>
@@ -51,18 +53,44 @@ __global__ __launch_bounds__(256, 3) void tail_fused_kernel(TailArgs a) {
   __shared__ __align__(16) uint16_t u2_s[kTfNHP * kTfRow];
   float* p_s = reinterpret_cast<float*>(u2_s);
   static_assert(kTfNPT * 16 * kTfPRow * 4 <= kTfNHP * kTfRow * 2, "tap table must fit into the u2 tile");
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  int t = blockIdx.x;
+  __shared__ __align__(16) float b2_s[256];
+  // Tile runs: a workgroup (three per CU) walks a contiguous run of tiles with its wave's 64 x 64 block of upconv2 weights in
+  // registers and the bias in LDS for the whole run.  One tile per workgroup re-read the 32 KB weight block from L2 for every
+  // 256 output pixels: 128 bytes per output pixel, six times the 22 bytes the pixel itself moves.
+  int t_begin, t_end;
   {                                                        // contiguous runs of tiles per XCD (halo rows of u1 hit its L2)
-    const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = t & 7, loc = t >> 3;
-    t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+    const int g = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = g & 7, loc = g >> 3;
+    const int ci = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+    t_begin = (int)((long long)ci * a.ntiles / nwg);
+    t_end = (int)((long long)(ci + 1) * a.ntiles / nwg);
   }
+  uint4 wf[2][4], wl0, wl1;
+  {
+    const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6, r0 = lane0 & 31, h0 = lane0 >> 5;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint16_t* wp = a.w2 + ((wave0 * 2 + q) * 32 + r0) * 64 + h0 * 8;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) wf[q][kk] = *reinterpret_cast<const uint4*>(wp + kk * 16);
+    }
+    wl0 = *reinterpret_cast<const uint4*>(a.wl + (lane0 & 15) * 64 + (lane0 >> 4) * 8);
+    wl1 = *reinterpret_cast<const uint4*>(a.wl + (lane0 & 15) * 64 + (lane0 >> 4) * 8 + 32);
+    b2_s[tid0] = a.b2 ? a.b2[tid0] : 0.f;
+  }
+  const float slope = a.slope[0];
+  const float blast = a.bl ? a.bl[0] : 0.f;
   const int per_img = a.tiles_x * a.tiles_y;
+  const int HH = 2 * a.H2, WW = 2 * a.W2;
+  __syncthreads();
+#pragma unroll 1
+  for (int t = t_begin; t < t_end; ++t) {
+  // lane-derived offsets are recomputed per tile: hoisted out of the loop they cost registers the tile body has no room for
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = tid >> 6;
   const int b = t / per_img;
   const int t2 = t - b * per_img;
   const int Y0 = (t2 / a.tiles_x) * kTfTH, X0 = (t2 % a.tiles_x) * kTfTW;
-  const int HH = 2 * a.H2, WW = 2 * a.W2;
   // this thread's output pixel: its current value (the base skip) is requested now and consumed at the very end
   const int oy = Y0 + (tid >> 5), ox = X0 + (tid & 31);
   const bool olive = oy < HH && ox < WW;
@@ -73,7 +101,7 @@ __global__ __launch_bounds__(256, 3) void tail_fused_kernel(TailArgs a) {
   {
     const int r = lane & 31, h = lane >> 5;
     const uint16_t* ub = reinterpret_cast<const uint16_t*>(a.u1.p) + (long long)b * a.u1.sb + h * 8;
-    uint4 kf[4][4], wf[2][4];
+    uint4 kf[4][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       int p = nt * 32 + r;
@@ -86,20 +114,13 @@ __global__ __launch_bounds__(256, 3) void tail_fused_kernel(TailArgs a) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) kf[nt][kk] = *reinterpret_cast<const uint4*>(up + kk * 16);
     }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const uint16_t* wp = a.w2 + ((wave * 2 + q) * 32 + r) * 64 + h * 8;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) wf[q][kk] = *reinterpret_cast<const uint4*>(wp + kk * 16);
-    }
-    const float slope = a.slope[0];
     const int sy = wave >> 1, sx = wave & 1;                // this wave's sub-pixel
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       float4 bq[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        bq[g] = a.b2 ? *reinterpret_cast<const float4*>(a.b2 + wave * 64 + q * 32 + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bq[g] = *reinterpret_cast<const float4*>(b2_s + wave * 64 + q * 32 + 8 * g + 4 * h);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         f32x16_t acc;
@@ -132,8 +153,6 @@ __global__ __launch_bounds__(256, 3) void tail_fused_kernel(TailArgs a) {
   // ---- GEMM 2: P[pixel][tap] = u2[pixel][:] . wl[tap][:] ---------------------------------------------------------------------
   {
     const int r16 = lane & 15, g4 = lane >> 4;
-    uint4 wl0 = *reinterpret_cast<const uint4*>(a.wl + r16 * 64 + g4 * 8);
-    uint4 wl1 = *reinterpret_cast<const uint4*>(a.wl + r16 * 64 + g4 * 8 + 32);
     f32x4_t pacc[(kTfNPT + 3) / 4];
 #pragma unroll
     for (int j = 0; j < (kTfNPT + 3) / 4; ++j) {
@@ -163,13 +182,15 @@ __global__ __launch_bounds__(256, 3) void tail_fused_kernel(TailArgs a) {
   {
     const int ty = tid >> 5, tx = tid & 31;
     if (olive) {
-      float s = base + (a.bl ? a.bl[0] : 0.f);
+      float s = base + blast;
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) s += p_s[((ty + dy) * kTfHW + tx + dx) * kTfPRow + dy * 3 + dx];
       *op = s;
     }
+  }
+  __syncthreads();                                         // the tap table is read: the next tile's u2 overwrites it
   }
 }
 
@@ -192,7 +213,18 @@ extern "C" int fcvsr_tail_fused(const fcvsr_view* u1, const void* w2, const floa
   a.out = to_view(*out); a.B = B; a.H2 = H2; a.W2 = W2;
   a.tiles_x = cdiv(2 * W2, kTfTW);
   a.tiles_y = cdiv(2 * H2, kTfTH);
-  dim3 grid(B * a.tiles_x * a.tiles_y);
+  a.ntiles = B * a.tiles_x * a.tiles_y;
+  static int wgs[64] = {0};                                // three workgroups per CU (48 KB of LDS, 168 registers each)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!wgs[dev]) {
+    hipDeviceProp_t prop;
+    wgs[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? 3 * prop.multiProcessorCount : 768;
+  }
+  static const int tpw = getenv("FCVSR_TAIL_TPW") ? atoi(getenv("FCVSR_TAIL_TPW")) : 0;   // tiles per workgroup (experiments)
+  int nwg = tpw > 0 ? cdiv(a.ntiles, tpw) : wgs[dev];
+  nwg = nwg < 8 ? 8 : nwg / 8 * 8;
+  dim3 grid(nwg < a.ntiles ? nwg : a.ntiles);
   hipStream_t st = (hipStream_t)stream;
   if (u1->dtype == FCVSR_BF16) hipLaunchKernelGGL(tail_fused_kernel<true>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(tail_fused_kernel<false>, grid, dim3(256), 0, st, a);

@@ -13,6 +13,7 @@
 // Replaces torch.fft.rfft2 / irfft2 (CVSR_freq.py:1452-1454, :1499, :1504) and the per-channel
 // fftn/fftshift/mask/ifftshift/ifftn(.real) loop of Split_freq (:2082-2090, via the symmetrised half-spectrum mask).
 #include <stdlib.h>
+#include <mutex>
 #include "common.h"
 
 namespace fcvsr {
@@ -788,6 +789,8 @@ static const float2* twiddle_table(int N, hipStream_t st) {
   struct Entry { int N; float2* p; };
   static Entry tabs[64][16];
   static int ntab[64] = {0};
+  static std::mutex mu;                                    // first use may come from several host threads (streamed harness)
+  std::lock_guard<std::mutex> lock(mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { set_error("fft: bad device index"); return nullptr; }
   for (int i = 0; i < ntab[dev]; ++i)

@@ -803,30 +803,33 @@ class Engine:
         # feat_extract is launched per frame group so that the two outer groups land in ONE batch-stacked tensor: the first
         # two MGAA calls of the reference (same weights, independent inputs f1 and f3, :2623-2624) run as one call on 2B.
         adt = self._tdt()
-        f13 = self._new(dev, 2 * B, H, W, 3 * n, dtype=adt)      # [f1 of every clip | f3 of every clip]
         f2 = self._new(dev, B, H, W, n, dtype=adt)
         cin = T * Cimg
         if adt != torch.float32 and cin == 7 and n == 64 and getattr(m, "fast_feat", True):
-            # the whole 3x3 patch fits one K = 64 GEMM step: dedicated kernel, the 7 output blocks go straight to f1 | f2 | f3
+            # the whole 3x3 patch fits one K = 64 GEMM step: dedicated kernel, the 7 output blocks go straight to their tensors.
+            # The three inputs of the stacked MGAA call are three DENSE tensors (2B,H,W,n) = [clip's group 1 | clip's group 3],
+            # not channel slices of one 3n-channel tensor: every later reader (FFT rows, IAC taps, conv_KP, conv3's residual)
+            # then streams whole DRAM pages instead of a third of each.
+            p13 = self._new(dev, 3, 2 * B, H, W, n, dtype=adt)
             wf, bf = self._feat_weights()
             xv = view(xin)
             nb = 7 * n // 64
             P = C.c_void_p * nb
-            es = f13.element_size()
-            f3_ptr = f13.data_ptr() + B * H * W * 3 * n * es
-            ptrs = [f13.data_ptr()] * 3 + [f2.data_ptr()] + [f3_ptr] * 3
-            strides = [3 * n] * 3 + [n] + [3 * n] * 3
-            choff = [0, 64, 128, 0, 0, 64, 128]
+            ptrs = [p13[k, :B].data_ptr() for k in range(3)] + [f2.data_ptr()] + [p13[k, B:].data_ptr() for k in range(3)]
             check(L.fcvsr_feat_extract(C.byref(xv), B, H, W, wf.data_ptr(), ptr(bf), nb, P(*ptrs),
-                                       (C.c_int64 * nb)(*strides), (C.c_int32 * nb)(*choff), self._code(adt), st),
+                                       (C.c_int64 * nb)(*([n] * nb)), (C.c_int32 * nb)(*([0] * nb)), self._code(adt), st),
                   "fcvsr_feat_extract")
+            x1s, x2s, x3s = p13[0], p13[1], p13[2]
         else:
+            f13 = self._new(dev, 2 * B, H, W, 3 * n, dtype=adt)  # [f1 of every clip | f3 of every clip]
             self._conv("feat_extract.0", [xin], f13[:B], force_f16=True, rows=(0, 3 * n))
             self._conv("feat_extract.0", [xin], f13[B:], force_f16=True, rows=(4 * n, 7 * n))
             self._conv("feat_extract.0", [xin], f2, force_f16=True, rows=(3 * n, 4 * n))
+            x1s, x2s, x3s = f13[..., :n], f13[..., n:2 * n], f13[..., 2 * n:]
         if self.taps is not None:
-            self._tap("feat", torch.cat([f13[:B].float(), f2.float(), f13[B:].float()], dim=3))
-        a13 = self._mgaa(f13[..., :n], f13[..., n:2 * n], f13[..., 2 * n:], "13")
+            self._tap("feat", torch.cat([x1s[:B].float(), x2s[:B].float(), x3s[:B].float(), f2.float(),
+                                         x1s[B:].float(), x2s[B:].float(), x3s[B:].float()], dim=3))
+        a13 = self._mgaa(x1s, x2s, x3s, "13")
         if self.taps is not None:                                  # split the stacked taps back into calls "1" and "3"
             for k in [k for k in self.taps if k.startswith("mgaa13.")]:
                 v = self.taps.pop(k)

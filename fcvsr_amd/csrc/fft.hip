@@ -572,8 +572,12 @@ __device__ __forceinline__ void load_twiddles(float2* tw, const float2* tab, int
 }
 
 // ---- columns, two stages: lane = (butterfly j, channel l) -------------------------------------------------------------------
-template <int R1, int R2, bool INV>
-__global__ __launch_bounds__(512) void fft_cols2_kernel(const float* in, float* out, long long ps, int im_off, int re_off, int n,
+// MASK is a template parameter and the waves-per-SIMD range is pinned: with a run-time mask test every (mask, re, im) load
+// triple sat in its own block, and hipcc, free to chase a higher occupancy than the LDS footprint allows anyway, kept the
+// loads of the row kernels in groups of four with a full wait between groups.
+template <int R1, int R2, bool INV, bool MASK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6)))
+void fft_cols2_kernel(const float* in, float* out, long long ps, int im_off, int re_off, int n,
                                                         int Wf, int logL, const float* mask, const float2* twtab, int nbatch) {
   constexpr int N = R1 * R2;
   extern __shared__ __align__(16) float lds[];
@@ -589,17 +593,20 @@ __global__ __launch_bounds__(512) void fft_cols2_kernel(const float* in, float* 
   const int l = threadIdx.x & (L - 1), j = threadIdx.x >> logL;
   const int c = chunk * L + l;
   const bool live = c < n;
-  const long long col0 = ((long long)b * N * Wf + kx) * ps + c;
+  const long long col0 = ((long long)b * N * Wf + kx) * ps + (live ? c : 0);   // dead lanes load channel 0 and discard it
   const long long rstride = (long long)Wf * ps;
   if (j < R2) {
     Cx v[R1];
+    float mk[R1];
 #pragma unroll
     for (int q = 0; q < R1; ++q) {
       const int y = j + q * R2;
       const float* px = in + col0 + (long long)y * rstride;
-      const float m = mask ? mask[y * Wf + kx] : 1.f;
-      v[q] = live ? Cx{px[re_off] * m, px[im_off] * m} : Cx{0.f, 0.f};
+      mk[q] = MASK ? mask[y * Wf + kx] : 1.f;
+      v[q] = Cx{px[re_off], px[im_off]};
     }
+#pragma unroll
+    for (int q = 0; q < R1; ++q) v[q] = live ? (MASK ? Cx{v[q].r * mk[q], v[q].i * mk[q]} : v[q]) : Cx{0.f, 0.f};
     Dft<R1, INV>::run(v);
 #pragma unroll
     for (int p = 0; p < R1; ++p) {
@@ -655,7 +662,9 @@ __global__ __launch_bounds__(512, 4) void rfft_rows2_kernel(View src, int n, int
   const int ca = chunk * 2 * L + 2 * l;
   const bool live = ca < n && j < R2;                             // n is even on this path
   // addresses = wave-uniform 64-bit base (line, chunk, q) + one 32-bit lane offset (host checks W * sx < 2^31)
-  const int lane_off = j * (int)src.sx + 2 * l;
+  // loads are unconditional (dead lanes read the row's first pair and discard it): predicated, every 16-bit load + unpack
+  // became its own basic block and the 16 loads of a lane were issued one round trip after the other
+  const int lane_off = live ? j * (int)src.sx + 2 * l : 0;
   auto issue = [&](const int row, Cx* v) {
     const int b = row / H, y = row - b * H;
     const long long sp = (long long)b * src.sb + (long long)y * src.sy + chunk * 2 * L;
@@ -663,7 +672,8 @@ __global__ __launch_bounds__(512, 4) void rfft_rows2_kernel(View src, int n, int
     for (int q = 0; q < R1; ++q) {
       const float* bq = SDT == FCVSR_F32 ? src.p + (sp + (long long)q * R2 * src.sx)
                                          : reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(src.p) + (sp + (long long)q * R2 * src.sx));
-      v[q] = live ? ld_pair<SDT>(bq, lane_off) : Cx{0.f, 0.f};
+      const Cx ld = ld_pair<SDT>(bq, lane_off);
+      v[q] = live ? ld : Cx{0.f, 0.f};
     }
   };
   {
@@ -727,20 +737,23 @@ __global__ __launch_bounds__(512, 4) void irfft_rows2_kernel(const float* spec, 
   const bool live = ca < n;
   auto issue = [&](const int row, Cx* v) {                         // Hermitian extension + two-for-one packing: Z = Xa + i Xb
     const float* ip = spec + ((long long)row * Wf) * ps + chunk * 2 * L;      // wave-uniform; lane part below is 32-bit
+    const bool on = live && j < R2;
+    float2 re[R1], im[R1];                                         // all 2 R1 loads first, then the packing arithmetic
+#pragma unroll
+    for (int q = 0; q < R1; ++q) {
+      const int k = j + q * R2;
+      const int kk = (k <= N / 2) ? k : N - k;
+      const int lo = on ? kk * (int)ps + 2 * l : 0;               // unconditional loads (see rfft_rows2_kernel)
+      re[q] = *reinterpret_cast<const float2*>(ip + re_off + lo);   // (Re Xa, Re Xb)
+      im[q] = *reinterpret_cast<const float2*>(ip + im_off + lo);   // (Im Xa, Im Xb)
+    }
 #pragma unroll
     for (int q = 0; q < R1; ++q) {
       const int k = j + q * R2;
       const int kk = (k <= N / 2) ? k : N - k;
       const float sgn = (k > N / 2) ? -1.f : 1.f;
       const float keep = ((kk == 0) || ((N % 2 == 0) && kk == N / 2)) ? 0.f : sgn;   // imag parts: dropped at DC / Nyquist
-      if (live && j < R2) {
-        const int lo = kk * (int)ps + 2 * l;
-        const float2 re = *reinterpret_cast<const float2*>(ip + re_off + lo);   // (Re Xa, Re Xb)
-        const float2 im = *reinterpret_cast<const float2*>(ip + im_off + lo);   // (Im Xa, Im Xb)
-        v[q] = Cx{re.x - keep * im.y, keep * im.x + re.y};
-      } else {
-        v[q] = Cx{0.f, 0.f};
-      }
+      v[q] = on ? Cx{re[q].x - keep * im[q].y, keep * im[q].x + re[q].y} : Cx{0.f, 0.f};
     }
   };
   {
@@ -848,10 +861,12 @@ static int launch_cols2(const TwoStage& ts, const float* in, float* out, long lo
   const dim3 grid(cdiv(n, L), (B * Wf + 7) / 8 * 8), block((rmax * L + 63) / 64 * 64);
   const size_t lds = 8ull * ts.N * L + 8ull * ts.N;
 #define FCVSR_COLS2(A_, B_)                                                                                                 \
-  if (inverse) hipLaunchKernelGGL((fft_cols2_kernel<A_, B_, true>), grid, block, lds, st, in, out, ps, im_off, re_off, n,   \
-                                  Wf, logL, mask, tw, B);                                                                    \
-  else hipLaunchKernelGGL((fft_cols2_kernel<A_, B_, false>), grid, block, lds, st, in, out, ps, im_off, re_off, n, Wf,      \
-                          logL, mask, tw, B)
+  if (inverse && mask) hipLaunchKernelGGL((fft_cols2_kernel<A_, B_, true, true>), grid, block, lds, st, in, out, ps, im_off, \
+                                          re_off, n, Wf, logL, mask, tw, B);                                                 \
+  else if (inverse) hipLaunchKernelGGL((fft_cols2_kernel<A_, B_, true, false>), grid, block, lds, st, in, out, ps, im_off,   \
+                                       re_off, n, Wf, logL, mask, tw, B);                                                    \
+  else hipLaunchKernelGGL((fft_cols2_kernel<A_, B_, false, false>), grid, block, lds, st, in, out, ps, im_off, re_off, n,   \
+                          Wf, logL, mask, tw, B)
   FCVSR_FFT2_DISPATCH(ts, FCVSR_COLS2);
 #undef FCVSR_COLS2
   return 0;

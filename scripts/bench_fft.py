@@ -5,8 +5,10 @@ from fcvsr_amd import hip
 L = hip.lib()
 B, H, W, n = int(os.environ.get("B", "8")), 180, 320, 64
 Wf = W // 2 + 1
-src = torch.rand(B, H, W, n, device="cuda"); spec = torch.empty(B, H, Wf, 2 * n, device="cuda"); work = torch.empty_like(spec)
-dst = torch.empty_like(src); mask = torch.rand(H, Wf, device="cuda")
+src = torch.rand(B, H, W, n, device="cuda")
+if os.environ.get("SRC", "f32") == "bf16": src = src.to(torch.bfloat16)
+spec = torch.empty(B, H, Wf, 2 * n, device="cuda"); work = torch.empty_like(spec)
+dst = torch.empty(B, H, W, n, device="cuda"); mask = torch.rand(H, Wf, device="cuda")
 sv, dv = hip.view(src), hip.view(dst)
 def t(fn, iters=20):
     for _ in range(3): fn()

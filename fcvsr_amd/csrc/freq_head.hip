@@ -82,9 +82,9 @@ __global__ __launch_bounds__(256, 4) void freq_head_kernel(FreqHeadArgs a) {
       float4 v[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int pix = flat0 + p0 + i * 16;
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pix < npix) v[i] = *reinterpret_cast<const float4*>(sb + (long long)pix * a.sx);
+        int pix = flat0 + p0 + i * 16;                   // clamped, not predicated (predicated loads were issued one
+        pix = pix < npix ? pix : npix - 1;               // round trip after the other); rows past the end are never stored
+        v[i] = *reinterpret_cast<const float4*>(sb + (long long)pix * a.sx);
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(A_s + (p0 + i * 16) * kFhLD + q * 4) = cvt4<true>(v[i]);
@@ -94,9 +94,9 @@ __global__ __launch_bounds__(256, 4) void freq_head_kernel(FreqHeadArgs a) {
       uint4 v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int pix = flat0 + p0 + i * 32;
-        v[i] = make_uint4(0, 0, 0, 0);
-        if (pix < npix) v[i] = *reinterpret_cast<const uint4*>(sb + (long long)pix * a.sx);
+        int pix = flat0 + p0 + i * 32;
+        pix = pix < npix ? pix : npix - 1;
+        v[i] = *reinterpret_cast<const uint4*>(sb + (long long)pix * a.sx);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(A_s + (p0 + i * 32) * kFhLD + q * 8) = v[i];

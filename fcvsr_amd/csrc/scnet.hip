@@ -794,12 +794,17 @@ __global__ __launch_bounds__(256) void gc_partial16_levels_kernel(GcPartArgs a) 
   const float4 w0 = *reinterpret_cast<const float4*>(a.wmask + oct * 8), w1 = *reinterpret_cast<const float4*>(a.wmask + oct * 8 + 4);
   float v[4][8], logit[4];
   bool ok[4];
+  uint4 rawv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                            // the four loads first, unconditional (clamped): predicated, each
+    const int py = ty0 + j, px = tx0 + ps;                 // load + conversion was its own block and its own round trip
+    ok[j] = py < L.H && px < L.W;
+    const int cy = py < L.H ? py : L.H - 1, cx = px < L.W ? px : L.W - 1;
+    rawv[j] = *reinterpret_cast<const uint4*>(L.r + (((long long)b * L.H + cy) * L.W + cx) * 64 + oct * 8);
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int py = ty0 + j, px = tx0 + ps;
-    ok[j] = py < L.H && px < L.W;
-    uint4 raw = make_uint4(0, 0, 0, 0);
-    if (ok[j]) raw = *reinterpret_cast<const uint4*>(L.r + (((long long)b * L.H + py) * L.W + px) * 64 + oct * 8);
+    const uint4 raw = ok[j] ? rawv[j] : make_uint4(0, 0, 0, 0);
     cvt16x4_to_f32<BF16>(make_uint2(raw.x, raw.y), v[j]);
     cvt16x4_to_f32<BF16>(make_uint2(raw.z, raw.w), v[j] + 4);
     float p = v[j][0] * w0.x + v[j][1] * w0.y + v[j][2] * w0.z + v[j][3] * w0.w + v[j][4] * w1.x + v[j][5] * w1.y + v[j][6] * w1.z + v[j][7] * w1.w;

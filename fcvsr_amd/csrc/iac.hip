@@ -353,9 +353,14 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
     int gy = oy0 + hy - 1, gx = ox0 + hx - 1;
     gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
     gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
-    const View off = a.d[sdir].off;
-    const float* op = off.p + (long long)bb * off.sb + (long long)gy * off.sy + (long long)gx * off.sx;
-    return make_float2(op[0], op[off.sc]);
+    // a.d[sdir] with a lane-dependent sdir is a VECTOR load from the kernel-argument block (and a round trip of its own
+    // before the offsets can even be requested): select between the two directions' scalar fields instead
+    const bool d1 = sdir != 0;
+    const float* op0 = d1 ? a.d[1].off.p : a.d[0].off.p;
+    const long long osb = d1 ? a.d[1].off.sb : a.d[0].off.sb, osy = d1 ? a.d[1].off.sy : a.d[0].off.sy;
+    const long long osx = d1 ? a.d[1].off.sx : a.d[0].off.sx, osc = d1 ? a.d[1].off.sc : a.d[0].off.sc;
+    const float* op = op0 + (long long)bb * osb + (long long)gy * osy + (long long)gx * osx;
+    return make_float2(op[0], op[osc]);
   };
   float2 off_next = make_float2(0.f, 0.f);
   if (t_begin < t_end) off_next = load_off(t_begin, threadIdx.x);
@@ -459,7 +464,8 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
     int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
     gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
     gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
-    const View prev = a.d[sdir].prev;
+    const int psy = (int)(sdir ? a.d[1].prev.sy : a.d[0].prev.sy);    // scalar fields selected per lane (no kernarg vector load);
+    const int psx = (int)(sdir ? a.d[1].prev.sx : a.d[0].prev.sx);    // 32-bit offsets inside one image (host checks H*sy < 2^31)
     const float fx = (float)gx + off_next.x;
     const float fy = (float)gy + off_next.y;
     const float x0f = floorf(fx), y0f = floorf(fy);
@@ -467,7 +473,6 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
     const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
     const bool sane = (fx > -2.f) && (fx < (float)W + 1.f) && (fy > -2.f) && (fy < (float)H + 1.f);
     const int x0 = sane ? (int)x0f : -4, y0 = sane ? (int)y0f : -4;
-    const int psy = (int)prev.sy, psx = (int)prev.sx;   // 32-bit offsets inside one image (host checks H*sy < 2^31)
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
 #pragma unroll

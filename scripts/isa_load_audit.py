@@ -16,7 +16,7 @@ def main(src, filt="", nmax=40):
     for k in re.findall(r"^(_Z\w+):", s, re.M):
         i = s.index("\n" + k + ":")
         blk = s[i:]
-        if "s_endpgm" not in blk or ".amdhsa_kernel" not in blk[:blk.index("s_endpgm") + 20000]:
+        if "s_endpgm" not in blk:
             continue
         body = blk[:blk.index("s_endpgm")]
         name = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip()

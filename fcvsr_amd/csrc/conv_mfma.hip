@@ -200,8 +200,25 @@ __device__ __forceinline__ void epilogue_oct(const EpiCtx& e, float4 va, float4 
   *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.p) + o + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 
+// a wave-uniform 64-bit value pinned to scalar registers (so that a per-lane select between such values stays a v_cndmask
+// and is not folded back into a load through a selected address)
+__device__ __forceinline__ long long uniform64(long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ long long sel3(int i, long long a, long long b, long long c) { return i == 0 ? a : (i == 1 ? b : c); }
+// loads through a pointer rebuilt from integers must be typed global: generic pointers compile to flat_load, which also
+// turns every counted lgkmcnt wait of the kernel into a full one
+typedef unsigned __attribute__((ext_vector_type(4))) cm_u32x4_t;
+typedef float __attribute__((ext_vector_type(4))) cm_f32x4_t;
+typedef __attribute__((address_space(1))) cm_u32x4_t cm_guint4_t;
+typedef __attribute__((address_space(1))) cm_f32x4_t cm_gfloat4_t;
+__device__ __forceinline__ uint4 gld_u4(long long addr) { const cm_u32x4_t v = *reinterpret_cast<const cm_guint4_t*>((unsigned long long)addr); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float4 gld_f4(long long addr) { const cm_f32x4_t v = *reinterpret_cast<const cm_gfloat4_t*>((unsigned long long)addr); return make_float4(v.x, v.y, v.z, v.w); }
+
 template <bool BF16, int NT, int KS, int MW, bool WD>
 __global__ __launch_bounds__(256, MW == 1 ? (WD ? (NT == 128 ? 2 : 3) : (NT == 128 ? 3 : 4)) : 2) void conv_mfma_kernel(MfmaArgs a) {
+  constexpr bool FLAT = KS == 1;                     // the host sets a.flat exactly for the 1x1 kernels
   constexpr int kTH = 4 * MW;                       // MW tile rows (M-fragments) per wave
   constexpr int PAD = KS / 2;
   constexpr int HH = kTH + 2 * PAD, HWD = kTW + 2 * PAD;
@@ -281,28 +298,41 @@ __global__ __launch_bounds__(256, MW == 1 ? (WD ? (NT == 128 ? 2 : 3) : (NT == 1
       const bool cok = (c < a.cin_total) && !(a.dbg & 1);
       int s_ = 0, cl = c;
       if (cl >= a.seg_c[0]) { cl -= a.seg_c[0]; s_ = 1; if (cl >= a.seg_c[1]) { cl -= a.seg_c[1]; s_ = 2; } }
-      const View sv = G.src[cok ? s_ : 0];
-      const float* sbase = sv.p + (a.flat ? 0ll : (long long)b * sv.sb) + cl;
+      // The lane's source depends on its channel quad: G.src[s_] with a lane-dependent index is a VECTOR load from the
+      // kernel-argument block; the three views' scalar fields are selected per lane instead.  The pixel loads are
+      // unconditional (clamped coordinates, zeroed afterwards): predicated, each load of the unrolled group was its own
+      // block and its own memory round trip.
+      const int si = cok ? s_ : 0;
+      const long long sp0 = sel3(si, uniform64((long long)G.src[0].p), uniform64((long long)G.src[1].p), uniform64((long long)G.src[2].p));
+      const long long ssb = sel3(si, uniform64(G.src[0].sb), uniform64(G.src[1].sb), uniform64(G.src[2].sb));
+      const long long ssy = sel3(si, uniform64(G.src[0].sy), uniform64(G.src[1].sy), uniform64(G.src[2].sy));
+      const long long ssx = sel3(si, uniform64(G.src[0].sx), uniform64(G.src[1].sx), uniform64(G.src[2].sx));
+      const long long sbase = sp0 + 4 * ((FLAT ? 0ll : (long long)b * ssb) + (cok ? cl : 0));      // byte address
       constexpr int UNR = 8;
 #pragma unroll 1
       for (int it0 = 0; it0 < ITERS; it0 += UNR) {
         float4 v[UNR];
+        bool ok[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           const int hp = (tid >> 4) + (it0 + u) * 16;
-          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (cok && hp < NHP) {
-            if (a.flat) {
-              const long long p = flat0 + hp;
-              if (p < npix) v[u] = *reinterpret_cast<const float4*>(sbase + p * sv.sx);
-            } else {
-              const int hy = hp / HWD, hx = hp - hy * HWD;     // HWD is a compile-time constant (mul-shift)
-              const int iy = ty0 + hy - PAD, ix = tx0 + hx - PAD;
-              if (iy >= 0 && iy < G.H && ix >= 0 && ix < G.W)
-                v[u] = *reinterpret_cast<const float4*>(sbase + (long long)iy * sv.sy + (long long)ix * sv.sx);
-            }
+          long long off;
+          if (FLAT) {
+            const long long p = flat0 + hp;
+            ok[u] = cok && hp < NHP && p < npix;
+            off = (p < npix ? p : npix - 1) * ssx;
+          } else {
+            const int hy = hp / HWD, hx = hp - hy * HWD;     // HWD is a compile-time constant (mul-shift)
+            const int iy = ty0 + hy - PAD, ix = tx0 + hx - PAD;
+            ok[u] = cok && hp < NHP && iy >= 0 && iy < G.H && ix >= 0 && ix < G.W;
+            const int cy = iy < 0 ? 0 : (iy > G.H - 1 ? G.H - 1 : iy), cx = ix < 0 ? 0 : (ix > G.W - 1 ? G.W - 1 : ix);
+            off = (long long)cy * ssy + (long long)cx * ssx;
           }
+          v[u] = gld_f4(sbase + 4 * off);
         }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+          if (!ok[u]) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           const int hp = (tid >> 4) + (it0 + u) * 16;
@@ -318,28 +348,37 @@ __global__ __launch_bounds__(256, MW == 1 ? (WD ? (NT == 128 ? 2 : 3) : (NT == 1
       const bool cok = (c < a.cin_total) && !(a.dbg & 1);
       int s_ = 0, cl = c;
       if (cl >= a.seg_c[0]) { cl -= a.seg_c[0]; s_ = 1; if (cl >= a.seg_c[1]) { cl -= a.seg_c[1]; s_ = 2; } }
-      const View sv = G.src[cok ? s_ : 0];
-      const uint16_t* sbase = reinterpret_cast<const uint16_t*>(sv.p) + (a.flat ? 0ll : (long long)b * sv.sb) + cl;
+      const int si = cok ? s_ : 0;                     // scalar view fields selected per lane, unconditional loads (see above)
+      const long long sp0 = sel3(si, uniform64((long long)G.src[0].p), uniform64((long long)G.src[1].p), uniform64((long long)G.src[2].p));
+      const long long ssb = sel3(si, uniform64(G.src[0].sb), uniform64(G.src[1].sb), uniform64(G.src[2].sb));
+      const long long ssy = sel3(si, uniform64(G.src[0].sy), uniform64(G.src[1].sy), uniform64(G.src[2].sy));
+      const long long ssx = sel3(si, uniform64(G.src[0].sx), uniform64(G.src[1].sx), uniform64(G.src[2].sx));
+      const long long sbase = sp0 + 2 * ((FLAT ? 0ll : (long long)b * ssb) + (cok ? cl : 0));      // byte address
       constexpr int UNR = 8;
 #pragma unroll 1
       for (int it0 = 0; it0 < ITERS; it0 += UNR) {
         uint4 v[UNR];
+        bool ok[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           const int hp = (tid >> 3) + (it0 + u) * 32;
-          v[u] = make_uint4(0, 0, 0, 0);
-          if (cok && hp < NHP) {
-            if (a.flat) {
-              const long long p = flat0 + hp;
-              if (p < npix) v[u] = *reinterpret_cast<const uint4*>(sbase + p * sv.sx);
-            } else {
-              const int hy = hp / HWD, hx = hp - hy * HWD;
-              const int iy = ty0 + hy - PAD, ix = tx0 + hx - PAD;
-              if (iy >= 0 && iy < G.H && ix >= 0 && ix < G.W)
-                v[u] = *reinterpret_cast<const uint4*>(sbase + (long long)iy * sv.sy + (long long)ix * sv.sx);
-            }
+          long long off;
+          if (FLAT) {
+            const long long p = flat0 + hp;
+            ok[u] = cok && hp < NHP && p < npix;
+            off = (p < npix ? p : npix - 1) * ssx;
+          } else {
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int iy = ty0 + hy - PAD, ix = tx0 + hx - PAD;
+            ok[u] = cok && hp < NHP && iy >= 0 && iy < G.H && ix >= 0 && ix < G.W;
+            const int cy = iy < 0 ? 0 : (iy > G.H - 1 ? G.H - 1 : iy), cx = ix < 0 ? 0 : (ix > G.W - 1 ? G.W - 1 : ix);
+            off = (long long)cy * ssy + (long long)cx * ssx;
           }
+          v[u] = gld_u4(sbase + 2 * off);
         }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+          if (!ok[u]) v[u] = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           const int hp = (tid >> 3) + (it0 + u) * 32;

@@ -683,7 +683,10 @@ __global__ __launch_bounds__(256, NT == 128 ? 2 : 4) void conv3_lean_kernel(Mfma
           if (i < ITERS) {
             const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
             const bool ok = cok && (p0 + i * STEP < NHP) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
-            if (ok) v[u] = *reinterpret_cast<const uint4*>(sbase + (unsigned)off);
+            // unconditional (out-of-image / dead lanes read the image's first pixel and discard it): predicated loads of the
+            // f32-source variants were issued one round trip after the other
+            const uint4 ld = *reinterpret_cast<const uint4*>(sbase + (ok ? (unsigned)off : 0u));
+            if (ok) v[u] = ld;
             hx += STEP;
             off += STEP * ssx * ESZ;
             if (hx >= HWD) { hx -= HWD; ++hy; off += (ssy - HWD * ssx) * ESZ; }
@@ -983,8 +986,8 @@ __global__ __launch_bounds__(256, 4) void conv1_lean_kernel(MfmaArgs a) {
 #pragma unroll
       for (int i = 0; i < ITERS; ++i) {
         const int pix = flat0 + p0 + i * STEP;
-        v[i] = make_uint4(0, 0, 0, 0);
-        if (pix < npix) v[i] = *reinterpret_cast<const uint4*>(sbase + (size_t)((unsigned)pix * (unsigned)ssx) * ESZ);
+        const long long pc = pix < npix ? pix : npix - 1;            // clamped, not predicated (rows past the end are never stored)
+        v[i] = *reinterpret_cast<const uint4*>(sbase + (size_t)((unsigned)pc * (unsigned)ssx) * ESZ);
       }
 #pragma unroll
       for (int i = 0; i < ITERS; ++i) {

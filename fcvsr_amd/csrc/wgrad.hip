@@ -90,17 +90,26 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(WgradArgs a) {
 }
 
 // dw[co][ci][tap] = sum over slabs, in slab order
+// Threads walk the PARTIAL layout ([tap][ci][co], co fastest): every slab read is coalesced and only the n final writes are
+// scattered (with threads in dw order each lane read its own 64-byte sector per slab: 38 us for a 64 x 64 x 9 layer, 341
+// launches per training step).  Same summation order (slab 0, 1, ...) as before: bit-identical results.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
   const long long n = (long long)a.cout * a.cin * a.kh * a.kw;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
   const int taps = a.kh * a.kw;
-  const int tap = (int)(i % taps);
-  const int ci = (int)((i / taps) % a.cin);
-  const int co = (int)(i / ((long long)taps * a.cin));
+  const int co = (int)(j % a.cout);
+  const int ci = (int)((j / a.cout) % a.cin);
+  const int tap = (int)(j / ((long long)a.cout * a.cin));
   float s = 0.f;
-  for (int sl = 0; sl < a.n_slabs; ++sl) s += a.partial[(((long long)sl * taps + tap) * a.cin + ci) * a.cout + co];
-  a.dw[i] = s;
+  int sl = 0;
+  for (; sl + 4 <= a.n_slabs; sl += 4) {                 // four independent loads in flight, added in slab order
+    const float p0 = a.partial[(long long)sl * n + j], p1 = a.partial[(long long)(sl + 1) * n + j];
+    const float p2 = a.partial[(long long)(sl + 2) * n + j], p3 = a.partial[(long long)(sl + 3) * n + j];
+    s += p0; s += p1; s += p2; s += p3;
+  }
+  for (; sl < a.n_slabs; ++sl) s += a.partial[(long long)sl * n + j];
+  a.dw[((long long)co * a.cin + ci) * taps + tap] = s;
 }
 
 }  // namespace fcvsr

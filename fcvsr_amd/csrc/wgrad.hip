@@ -38,34 +38,42 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(WgradArgs a) {
   const long long p0 = (long long)slab * a.slab_pix;
   long long p1 = p0 + a.slab_pix;
   if (p1 > a.npix) p1 = a.npix;
+  __shared__ long long goff_s[kWgPx], xoff_s[kWgPx];       // element offsets of the 32 pixels' gy / shifted x records (-1: none)
   for (long long pc = p0; pc < p1; pc += kWgPx) {
+    __syncthreads();
+    // pixel -> (b, oy, ox) once per PIXEL (32 lanes, 32-bit divisions), not once per staged element: the 64-bit div / mod
+    // triple per element was most of this kernel's time (3 ms for conv_last0's and feat_extract's weight gradients)
+    if (tid < kWgPx) {
+      const long long p = pc + tid;
+      long long go = -1, xo = -1;
+      if (p < p1) {
+        const unsigned pp = (unsigned)p;                   // host checks npix < 2^31
+        const unsigned t = pp / (unsigned)a.Wo;
+        const int ox = (int)(pp - t * (unsigned)a.Wo);
+        const int b = (int)(t / (unsigned)a.Ho);
+        const int oy = (int)(t - (unsigned)b * (unsigned)a.Ho);
+        go = (long long)b * a.gy.sb + (long long)oy * a.gy.sy + (long long)ox * a.gy.sx;
+        const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) xo = (long long)b * a.x.sb + (long long)iy * a.x.sy + (long long)ix * a.x.sx;
+      }
+      goff_s[tid] = go;
+      xoff_s[tid] = xo;
+    }
     __syncthreads();
     // stage gy[pc .. pc+32)[co0 .. co0+16) and the tap-shifted x[..][ci0 .. ci0+64) (zeros outside the image / past the slab)
     for (int i = tid; i < kWgPx * kWgCo; i += 256) {
       const int q = i >> 4, c = i & 15;
-      const long long p = pc + q;
-      float v = 0.f;
-      if (p < p1 && co0 + c < a.cout) {
-        const int ox = (int)(p % a.Wo);
-        const int oy = (int)((p / a.Wo) % a.Ho);
-        const int b = (int)(p / ((long long)a.Wo * a.Ho));
-        v = a.gy.p[(long long)b * a.gy.sb + (long long)oy * a.gy.sy + (long long)ox * a.gy.sx + co0 + c];
-      }
-      gy_s[q][c] = v;
+      const long long go = goff_s[q];
+      const bool ok = go >= 0 && co0 + c < a.cout;
+      const float v = a.gy.p[(ok ? go : 0) + (ok ? co0 + c : 0)];
+      gy_s[q][c] = ok ? v : 0.f;
     }
     for (int i = tid; i < kWgPx * kWgCi; i += 256) {
       const int q = i >> 6, c = i & 63;
-      const long long p = pc + q;
-      float v = 0.f;
-      if (p < p1 && ci0 + c < a.cin) {
-        const int ox = (int)(p % a.Wo);
-        const int oy = (int)((p / a.Wo) % a.Ho);
-        const int b = (int)(p / ((long long)a.Wo * a.Ho));
-        const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-          v = a.x.p[(long long)b * a.x.sb + (long long)iy * a.x.sy + (long long)ix * a.x.sx + ci0 + c];
-      }
-      x_s[q][c] = v;
+      const long long xo = xoff_s[q];
+      const bool ok = xo >= 0 && ci0 + c < a.cin;
+      const float v = a.x.p[(ok ? xo : 0) + (ok ? ci0 + c : 0)];
+      x_s[q][c] = ok ? v : 0.f;
     }
     __syncthreads();
 #pragma unroll 8
@@ -130,6 +138,7 @@ extern "C" int fcvsr_conv2d_wgrad(const fcvsr_view* x, const fcvsr_view* gy, int
   FCVSR_CHECK_ARG(x->dtype == FCVSR_F32 && gy->dtype == FCVSR_F32 && x->sc == 1 && gy->sc == 1 && x->ptr && gy->ptr,
                   "x and gy must be channel-contiguous f32 views");
   FCVSR_CHECK_ARG(B > 0 && H > 0 && W > 0 && kh >= 1 && kw >= 1 && stride >= 1 && pad >= 0, "bad geometry");
+  FCVSR_CHECK_ARG((long long)B * H * W < (1ll << 31), "too many pixels for 32-bit pixel indices");
   WgradArgs a;
   a.x = to_view(*x);
   a.gy = to_view(*gy);

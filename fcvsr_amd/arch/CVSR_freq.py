@@ -210,6 +210,8 @@ class _GShiftBase(nn.Module):
         # 16-bit modes, 16-bit trunk: ContextBlock partials from the stored r in their own launch (the conv then runs on the
         # resident-weight kernel) instead of from the lean kernel's epilogue
         self.gc_separate = os.environ.get("FCVSR_GC_SEPARATE", "1") == "1"
+        # MultiFreq_Refinment band split: all masked inverse transforms in one call (spectrum columns read once)
+        self.fuse_bands = os.environ.get("FCVSR_FUSE_BANDS", "1") == "1"
         # 16-bit modes: BlockRCB's full-resolution level in one pass (R0 is never stored)
         self.fuse_rcb_l0 = os.environ.get("FCVSR_FUSE_RCB_L0", "1") == "1"
         # capture the launch sequence of a forward in a hipGraph (per input shape) and replay it

@@ -487,14 +487,21 @@ class Engine:
         par = self._par
         masks = self._mask(Q, H, W, dev)
         spec = self._new(dev, B, H, Wf, 2 * n)
-        work = self._new(dev, B, H, Wf, 2 * n)
+        work = self._new(dev, B, H, Wf, 2 * n)                   # (band-by-band path)
         xv = view(x)
         check(L.fcvsr_rfft2(C.byref(xv), B, H, W, n, spec.data_ptr(), 2 * n, 0, n, st), "fcvsr_rfft2")
         bands = self._new(dev, Q, B, H, W, n)
-        for q in range(Q):
-            bv = view(bands[q])
-            check(L.fcvsr_irfft2(spec.data_ptr(), 2 * n, 0, n, B, H, W, n, masks[q].data_ptr(), work.data_ptr(),
-                                 C.byref(bv), st), "fcvsr_irfft2")
+        if masks.is_contiguous() and getattr(m, "fuse_bands", True):
+            # all Q masked inverse transforms in one call: the spectrum columns are read once (fcvsr_irfft2_bands)
+            work = self._new(dev, Q, B, H, Wf, 2 * n)
+            bvs = (hip.View * Q)(*[view(bands[q]) for q in range(Q)])
+            check(L.fcvsr_irfft2_bands(spec.data_ptr(), 2 * n, 0, n, B, H, W, n, masks.data_ptr(), Q, work.data_ptr(), bvs, st),
+                  "fcvsr_irfft2_bands")
+        else:
+            for q in range(Q):
+                bv = view(bands[q])
+                check(L.fcvsr_irfft2(spec.data_ptr(), 2 * n, 0, n, B, H, W, n, masks[q].data_ptr(), work.data_ptr(),
+                                     C.byref(bv), st), "fcvsr_irfft2")
         freq = [bands[Q - 1 - i] for i in range(Q)]               # 'l2h' => reversed band list (:2204-2205)
         s_f = self._new(dev, B, H, W, n)
         s_o = self._new(dev, B, H, W, n)
@@ -730,7 +737,7 @@ class Engine:
             ns = max(1, min(int(getattr(m, "streams", 1)), B))
             flags = tuple(bool(getattr(m, f, True)) for f in ("trunk16", "fold_f1", "fuse_tail", "pool_first", "fuse_freq_mlp",
                                                               "fuse_freq_head", "fast_feat", "fuse_rcb_tail", "gc_separate", "fast_last",
-                                                              "fuse_rcb_l0"))
+                                                              "fuse_rcb_l0", "fuse_bands"))
             cfg = (tuple(x.shape[1:]), self.precision, str(dev), self._pack_epoch, flags)
             if ns > 1 and cfg not in self._warm:
                 # First pass of a configuration: re-packed weights, band masks and per-kernel attributes are created lazily

@@ -87,6 +87,7 @@ SIGNATURES = {
     "fcvsr_conv2d_mfma": [C.POINTER(ConvDesc), _I, _I, _VP],
     "fcvsr_rfft2": [_PV, _I, _I, _I, _I, _VP, _I64, _I, _I, _VP],
     "fcvsr_irfft2": [_VP, _I64, _I, _I, _I, _I, _I, _I, _VP, _VP, _PV, _VP],
+    "fcvsr_irfft2_bands": [_VP, _I64, _I, _I, _I, _I, _I, _I, _VP, _I, _VP, _PV, _VP],
     "fcvsr_corr_lookup": [_VP, _VP, _I64, _I, _I, _I, _I, _I, _I, _PV, _VP],
     "fcvsr_channel_sum": [_PV, _I, _I, _I, _VP, _VP, _I64, _VP],
     "fcvsr_ca_gate": [_VP, _F, _VP, _VP, _I, _I, _I, _VP, _VP],

@@ -129,6 +129,12 @@ int fcvsr_rfft2(const fcvsr_view* src, int B, int H, int W, int n,
                 float* spec, int64_t pix_stride, int im_off, int re_off, void* stream);
 int fcvsr_irfft2(const float* spec, int64_t pix_stride, int im_off, int re_off, int B, int H, int W, int n,
                  const float* mask, float* work, const fcvsr_view* dst, void* stream);
+/* Band split of MultiFreq_Refinment (reference :2082-2090) in one call: dst[m] = irfft2(spec * masks[m]) for m < n_bands.
+ * masks: n_bands contiguous (H,Wf) real masks; work: n_bands * B*H*Wf*pix_stride floats; dst: n_bands f32 views (B,H,W,>=n).
+ * When H has a two-stage factorisation the spectrum columns are read once for all bands (results identical to n_bands
+ * calls of fcvsr_irfft2, which is also the fallback). */
+int fcvsr_irfft2_bands(const float* spec, int64_t pix_stride, int im_off, int re_off, int B, int H, int W, int n,
+                       const float* masks, int n_bands, float* work, const fcvsr_view* dst, void* stream);
 
 /* feat_extract (:2589, Conv2d(Cin, n_blk*64, 3, 1, 1), Cin = 7: 9*Cin <= 64) as one K = 64 GEMM step per output tile.
  * x: (B,H,W,Cin) f32 view of the planar frames; w: [n_blk*64][64] f16, column k = tap*Cin + c (zero beyond 9*Cin);

@@ -681,3 +681,34 @@ def test_rcb_level0_equals_apply_then_xscale(dt, H, W):
     assert float((out.double() - ref).abs().max()) <= tol
     pd = F.avg_pool2d(Rd.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
     assert float((P.double() - pd).abs().max()) <= (2.0 ** -8 if dt == "bf16" else 2.0 ** -11) * float(pd.abs().max())
+
+
+@pytest.mark.parametrize("H,W,n,Q", [(180, 320, 64, 4), (64, 72, 12, 3), (20, 24, 8, 2)])
+def test_irfft2_bands_equals_band_by_band(H, W, n, Q):
+    """fcvsr_irfft2_bands (spectrum columns read once for all masks when H has a two-stage factorisation; otherwise the plain
+    loop) against Q calls of fcvsr_irfft2 with the same masks: bit-identical bands (reference Split_freq :2082-2090)."""
+    from fcvsr_amd import hip
+    L = hip.lib()
+    g0 = torch.Generator().manual_seed(H + W + n)
+    B, Wf = 2, W // 2 + 1
+    src = torch.randn(B, H, W, n, generator=g0).cuda()
+    spec = torch.empty(B, H, Wf, 2 * n, device="cuda")
+    sv = hip.view(src)
+    st = hip.stream_ptr()
+    hip.check(L.fcvsr_rfft2(C.byref(sv), B, H, W, n, spec.data_ptr(), 2 * n, 0, n, st), "rfft2")
+    masks = torch.rand(Q, H, Wf, generator=g0).cuda()
+    ref = torch.empty(Q, B, H, W, n, device="cuda")
+    work = torch.empty(B, H, Wf, 2 * n, device="cuda")
+    for q in range(Q):
+        bv = hip.view(ref[q])
+        hip.check(L.fcvsr_irfft2(spec.data_ptr(), 2 * n, 0, n, B, H, W, n, masks[q].data_ptr(), work.data_ptr(), C.byref(bv), st), "irfft2")
+    out = torch.full((Q, B, H, W, n), float("nan"), device="cuda")
+    workq = torch.empty(Q, B, H, Wf, 2 * n, device="cuda")
+    bvs = (hip.View * Q)(*[hip.view(out[q]) for q in range(Q)])
+    hip.check(L.fcvsr_irfft2_bands(spec.data_ptr(), 2 * n, 0, n, B, H, W, n, masks.data_ptr(), Q, workq.data_ptr(), bvs, st), "irfft2_bands")
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    # and against torch
+    sp = torch.complex(spec[..., n:], spec[..., :n])                    # [imag | real] packing
+    tref = torch.fft.irfft2(sp * masks[0][None, :, :, None], s=(H, W), dim=(1, 2))
+    assert float((out[0] - tref).abs().max()) <= 2e-5 * max(1.0, float(tref.abs().max()))

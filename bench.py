@@ -50,6 +50,8 @@ def stub_run(args, world, rank):
     """No-GPU rehearsal of the rank protocol (rendezvous, barrier, max-over-ranks, rank 0 prints one line)."""
     import torch
     import torch.distributed as dist
+    if os.environ.get("FCVSR_BENCH_FAIL_RANK") == str(rank):       # test hook: a rank that dies before the rendezvous
+        sys.exit(3)
     if world > 1:
         dist.init_process_group(args.backend if args.backend != "nccl" else "gloo")
     x = torch.zeros(args.batch, 7, 1, 8, 8)
@@ -92,12 +94,30 @@ def self_launch(n: int) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # a rank that dies (bad device ordinal, build missing, ...) must not leave the others waiting in a collective until some outer
+    # timeout: poll, and on the first failure stop the remaining ranks (exact PIDs of the children started above)
     rc = 0
-    for r, p in enumerate(procs):
-        c = p.wait()
-        if c != 0:
-            log(f"rank {r} exited with code {c}")
-            rc = rc or c
+    alive = dict(enumerate(procs))
+    while alive:
+        time.sleep(0.2)
+        for r, p in list(alive.items()):
+            c = p.poll()
+            if c is None:
+                continue
+            del alive[r]
+            if c != 0:
+                log(f"rank {r} exited with code {c}")
+                rc = rc or c
+        if rc and alive:
+            log(f"stopping the remaining ranks {sorted(alive)}")
+            for p in alive.values():
+                p.terminate()
+            for p in alive.values():
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
     return rc
 
 
@@ -128,6 +148,12 @@ def main():
                          "(metric 'stub'); used by tests/test_dist_cpu.py with --backend gloo")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if not args.stub and args.device is None:
+            import torch                                   # device_count() does not initialise the GPU
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                raise SystemExit(f"--gpus {args.gpus} but only {have} HIP device(s) are visible "
+                                 f"(rehearse N ranks on one GPU with --device 0)")
         sys.exit(self_launch(args.gpus))
 
     import numpy as np

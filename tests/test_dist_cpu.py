@@ -89,3 +89,20 @@ def test_bench_rejects_world_size_mismatch():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0
+
+
+def test_bench_self_launch_stops_all_ranks_when_one_dies():
+    """A rank that exits early (bad device ordinal, missing build, ...) must not leave the others blocked in the rendezvous:
+    the launcher stops them and returns the failing rank's code promptly."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FCVSR_BENCH_FAIL_RANK"] = "1"
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub",
+                        "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode != 0
+    assert time.time() - t0 < 120, "the surviving rank was left waiting"
+    assert "rank 1 exited with code 3" in p.stderr

@@ -136,10 +136,11 @@ __device__ __forceinline__ void res_stage(const int* tabL, const void* zeros, co
 
 // NCH = input-channel chunks of 64 (1 or 2); a workgroup owns CO = 64 / NCH output channels of every tile it visits.
 // MODE: 0 = f32 destination, 1 = 16-bit destination, 2 = 16-bit destination without residuals (the multiplying wave packs).
-// NSU: the activation's negative-side factor lies in [0, 1] (ReLU, LeakyReLU, none): act(x) = max(x, ns * x).
+// NSU: 1 = the activation's negative-side factor lies in [0, 1] (ReLU, LeakyReLU): act(x) = max(x, ns * x); 2 = no activation at
+// all (half of the BlockRCB layers): the multiply + max per value is skipped, same bits as max(x, 1 * x); 0 = general (PReLU).
 // Both are template parameters because hipcc re-merges wave-uniform run-time variants into one body with a scalar branch
 // per 4 values (SimplifyCFG hoists the common code of the arms): ~40 branches per tile in the epilogue.
-template <bool BF16, int MODE, int NCH, bool NSU>
+template <bool BF16, int MODE, int NCH, int NSU>
 __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResK a) {
   constexpr bool DST16 = MODE != 0;
   constexpr bool FAST = MODE == 2;
@@ -278,7 +279,8 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResK a) {
                 float v[4] = {acc[mf][j][4 * g] + b4.x, acc[mf][j][4 * g + 1] + b4.y, acc[mf][j][4 * g + 2] + b4.z,
                               acc[mf][j][4 * g + 3] + b4.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = NSU ? fmaxf(v[e], ns * v[e]) : fmaxf(v[e], 0.f) + ns * fminf(v[e], 0.f);
+                for (int e = 0; e < 4; ++e)
+                  if (NSU != 2) v[e] = NSU == 1 ? fmaxf(v[e], ns * v[e]) : fmaxf(v[e], 0.f) + ns * fminf(v[e], 0.f);
                 if (FAST) {
                   const uint2 pk = cvt4<BF16>(make_float4(v[0], v[1], v[2], v[3]));
                   acc[mf][j][2 * g] = __uint_as_float(pk.x);
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResK a) {
 
 bool conv3_res_supports(int cin, int cout) { return (cin == 64 && cout % 64 == 0) || (cin == 128 && cout % 32 == 0); }
 
-template <bool BF16, int MODE, int NCH, bool NSU>
+template <bool BF16, int MODE, int NCH, int NSU>
 static hipError_t launch_res(const ResArgs& a, hipStream_t st) {
   static int n_cu = 0;
   if (!n_cu) {
@@ -485,14 +487,19 @@ static hipError_t launch_res_mode(const ResArgs& a, bool dst16, hipStream_t st) 
   // act(x) = max(x, ns * x) needs 0 <= ns <= 1: known on the host for every activation but PReLU (slope in device memory)
   const bool nsu = a.act == FCVSR_ACT_NONE || a.act == FCVSR_ACT_RELU || (a.act == FCVSR_ACT_LEAKY && a.slope >= 0.f && a.slope <= 1.f);
   const int mode = !dst16 ? 0 : (a.n_res == 0 ? 2 : 1);
-  if (nsu) {
-    if (mode == 0) return launch_res<BF16, 0, NCH, true>(a, st);
-    if (mode == 1) return launch_res<BF16, 1, NCH, true>(a, st);
-    return launch_res<BF16, 2, NCH, true>(a, st);
+  if (a.act == FCVSR_ACT_NONE) {
+    if (mode == 0) return launch_res<BF16, 0, NCH, 2>(a, st);
+    if (mode == 1) return launch_res<BF16, 1, NCH, 2>(a, st);
+    return launch_res<BF16, 2, NCH, 2>(a, st);
   }
-  if (mode == 0) return launch_res<BF16, 0, NCH, false>(a, st);
-  if (mode == 1) return launch_res<BF16, 1, NCH, false>(a, st);
-  return launch_res<BF16, 2, NCH, false>(a, st);
+  if (nsu) {
+    if (mode == 0) return launch_res<BF16, 0, NCH, 1>(a, st);
+    if (mode == 1) return launch_res<BF16, 1, NCH, 1>(a, st);
+    return launch_res<BF16, 2, NCH, 1>(a, st);
+  }
+  if (mode == 0) return launch_res<BF16, 0, NCH, 0>(a, st);
+  if (mode == 1) return launch_res<BF16, 1, NCH, 0>(a, st);
+  return launch_res<BF16, 2, NCH, 0>(a, st);
 }
 
 hipError_t launch_conv3_res(const ResArgs& a, bool bf16, bool dst16, hipStream_t st) {

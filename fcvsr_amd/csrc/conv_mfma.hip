@@ -1479,7 +1479,8 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
         wa.stamps = (unsigned long long*)g_res_stamps;
       }
     }
-    FCVSR_NOTE_KERNEL("conv3_res_kernel<%s, %d, %d>", tf(mma_dtype == FCVSR_BF16), !a.dst16 ? 0 : (a.n_res == 0 ? 2 : 1), cin / 64);
+    FCVSR_NOTE_KERNEL("conv3_res_kernel<%s, %d, %d, %d>", tf(mma_dtype == FCVSR_BF16), !a.dst16 ? 0 : (a.n_res == 0 ? 2 : 1), cin / 64,
+                      a.act == FCVSR_ACT_NONE ? 2 : ((a.act == FCVSR_ACT_RELU || (a.act == FCVSR_ACT_LEAKY && a.slope >= 0.f && a.slope <= 1.f)) ? 1 : 0));
     e = launch_conv3_res(wa, mma_dtype == FCVSR_BF16, a.dst16 != 0, st);
     if (e != hipSuccess) {
       set_error("fcvsr_conv2d_mfma: resident-weight launch failed: %s", hipGetErrorString(e));

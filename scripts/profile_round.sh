@@ -10,7 +10,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats -d /tmp/pr_d -o d -- python3 
 cd $R
 python scripts/rocprof_summary.py $(find /tmp/pr_e -name "*results.db" | head -1) > $O/bf16_b16_eager1stream_kernel_stats.txt
 python scripts/rocprof_summary.py $(find /tmp/pr_d -name "*results.db" | head -1) > $O/bf16_b16_default_kernel_stats.txt
-KN="${1:-void fcvsr::conv3_res_kernel<true, 2, 1,}"
+KN="${1:-void fcvsr::conv3_res_kernel<true, 2, 1, 1>}"
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c

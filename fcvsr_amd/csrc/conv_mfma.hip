@@ -1418,7 +1418,9 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
             ((uintptr_t)d.res[q].ptr % 16) == 0;
     }
     rtiles += conv3_res_tiles(d.B, d.H, d.W);
-    if (res_ps) res = res && d.dst.c == d0.cout / 4 && (long long)d.B * d.dst.sb < (1ll << 29) && (long long)d.B * d.src[0].sb < (1ll << 29) &&
+    // (destination element offsets are formed in 32-bit arithmetic and widened before the byte scaling: < 2^30 elements keeps
+    // every intermediate positive; 16 clips of 720 x 1280 x 64 are 0.94 * 2^30)
+    if (res_ps) res = res && d.dst.c == d0.cout / 4 && (long long)d.B * d.dst.sb < (1ll << 30) && (long long)d.B * d.src[0].sb < (1ll << 29) &&
                       d.src[0].sc == 1 && ((uintptr_t)d.src[0].ptr % 16) == 0;
   }
   {

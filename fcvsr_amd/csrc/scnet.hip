@@ -267,7 +267,23 @@ __global__ void gc_stage2_levels_kernel(GcFinishArgs a, int C, const float* w1, 
     const int Cq = C / 4, R = blockDim.x / Cq;
     const int sub = threadIdx.x / Cq, cq = threadIdx.x % Cq;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = sub; k < nblk; k += R) {
+    // eight tiles' loads in flight per step, added in the same (ascending k) order as the rolled loop: identical sums.
+    // (rolled, every iteration waited for its own 16 bytes: ~225 dependent round trips for the full-resolution level)
+    int k = sub;
+    for (; k + 7 * R < nblk; k += 8 * R) {
+      float2 lo[8], hi[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float2* pr = reinterpret_cast<const float2*>(pb + (long long)(k + u * R) * (C + 2) + cq * 4);
+        lo[u] = pr[0]; hi[u] = pr[1];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float sc = scale[k + u * R];
+        acc.x = fmaf(lo[u].x, sc, acc.x); acc.y = fmaf(lo[u].y, sc, acc.y); acc.z = fmaf(hi[u].x, sc, acc.z); acc.w = fmaf(hi[u].y, sc, acc.w);
+      }
+    }
+    for (; k < nblk; k += R) {
       const float2* pr = reinterpret_cast<const float2*>(pb + (long long)k * (C + 2) + cq * 4);
       const float2 lo = pr[0], hi = pr[1];
       const float sc = scale[k];

@@ -51,8 +51,19 @@ static __global__ __launch_bounds__(kRedThreads) void reduce_stage2(const float*
   const int R = kRedThreads / C;
   const int sub = threadIdx.x / C, c = threadIdx.x % C;
   float s = 0.f;
-  if (sub < R)
-    for (int blk = sub; blk < nblk; blk += R) s += partial[((long long)kb * nblk + blk) * C + c];
+  if (sub < R) {
+    // eight loads in flight per step, added in ascending block order (the rolled loop waited for every single load)
+    const float* pp = partial + (long long)kb * nblk * C + c;
+    int blk = sub;
+    for (; blk + 7 * R < nblk; blk += 8 * R) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pp[(long long)(blk + u * R) * C];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; blk < nblk; blk += R) s += pp[(long long)blk * C];
+  }
   sm[threadIdx.x] = s;
   __syncthreads();
   if (threadIdx.x < C) {

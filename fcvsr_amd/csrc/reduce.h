@@ -23,7 +23,18 @@ __global__ __launch_bounds__(kRedThreads) void reduce_stage1(F f, int B, long lo
   if (sub < R) {
     const long long p0 = (long long)blk * kRedPix;
     const long long p1 = (p0 + kRedPix < npix) ? p0 + kRedPix : npix;
-    for (long long p = p0 + sub; p < p1; p += R) {
+    // eight pixels per step: their loads are issued together, the additions keep the ascending-pixel order
+    long long p = p0 + sub;
+    for (; K == 1 && p + 7 * R < p1; p += 8 * R) {        // (the two-value DivEnh expression measured slower unrolled: K == 1 only)
+      float v[8][K];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) f(b, p + (long long)u * R, c, v[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] += v[u][k];
+    }
+    for (; p < p1; p += R) {
       float v[K];
       f(b, p, c, v);
 #pragma unroll

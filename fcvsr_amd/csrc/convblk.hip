@@ -147,10 +147,15 @@ __global__ __launch_bounds__(256) void convblk_tail_kernel2(const float4* u, con
   const float o3 = fmaf(uu.w, gate_s[3], uu.w) * ss.w;
   float* px = spec + ((long long)b * HW + pix) * ps;
   const int gi = (g0 + dir * g_stride) * 2;
-  px[re_off + gi] = o0;
-  px[re_off + gi + 1] = o1;
-  px[im_off + gi] = o2;
-  px[im_off + gi + 1] = o3;
+  if (((ps | re_off | im_off) & 1) == 0 && (reinterpret_cast<uintptr_t>(spec) & 7) == 0) {   // gi is even: 8-byte pairs
+    *reinterpret_cast<float2*>(px + re_off + gi) = make_float2(o0, o1);
+    *reinterpret_cast<float2*>(px + im_off + gi) = make_float2(o2, o3);
+  } else {
+    px[re_off + gi] = o0;
+    px[re_off + gi + 1] = o1;
+    px[im_off + gi] = o2;
+    px[im_off + gi + 1] = o3;
+  }
 }
 
 template <int K>

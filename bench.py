@@ -65,13 +65,49 @@ def stub_run(args, world, rank):
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # the training sub-record's rank protocol (collective failure agreement) on CPU tensors
+    train = None
+    if not args.no_train:
+        g = torch.zeros(16)
+
+        def coll():
+            if world > 1:
+                dist.all_reduce(g)
+        err, done, _ = guarded_steps(lambda it: g.add_(1.0), coll, (lambda: dist.barrier()) if world > 1 else (lambda: None),
+                                     3, world, rank, "cpu", "gloo")
+        train = {"error": err, "steps_done": done} if err is not None else {"steps_done": done, "world": world}
     if rank == 0:
         print(json.dumps({"metric": "stub", "value": world * args.batch * args.steps / max(float(t), 1e-9), "unit": "frames/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "data": "stub", "scaling": "weak"}),
-              flush=True)
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "data": "stub", "scaling": "weak",
+                          "train": train}), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def visible_gpu_count():
+    """GPUs this process tree may use, WITHOUT touching the HIP runtime: the *_VISIBLE_DEVICES lists if set, else the KFD
+    topology nodes that have SIMDs (CPU nodes have simd_count 0).  None when neither source exists (no amdgpu driver)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    base = os.environ.get("FCVSR_KFD_TOPOLOGY", "/sys/class/kfd/kfd/topology/nodes")
+    try:
+        nodes = os.listdir(base)
+    except OSError:
+        return None
+    n = 0
+    for d in nodes:
+        try:
+            with open(os.path.join(base, d, "properties")) as f:
+                for ln in f:
+                    if ln.startswith("simd_count"):
+                        n += int(ln.split()[1]) > 0
+                        break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def free_port() -> int:
@@ -121,6 +157,148 @@ def self_launch(n: int) -> int:
     return rc
 
 
+def build_info():
+    """Compiler flags the loaded library was built with (the packed-FP32 guard of fcvsr_amd/build.py is part of the result)."""
+    from fcvsr_amd import build as Bd
+    return {"flags": " ".join(Bd.FLAGS), "slp_files": sorted(Bd.SLP_FILES), "no_slp_default": True}
+
+
+def all_ranks_ok(ok: bool, world: int, dev, backend: str) -> bool:
+    """Collective agreement on success: MIN over ranks of a 0/1 flag.  Every rank calls it the same number of times whatever
+    happened locally, so a local failure never leaves the others waiting inside a later collective."""
+    if world <= 1:
+        return ok
+    import torch
+    import torch.distributed as dist
+    f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(f, op=dist.ReduceOp.MIN)
+    return bool(int(f.item()) == 1)
+
+
+def guarded_steps(local_fn, collective_fn, after_warmup_fn, nt, world, rank, dev, backend, err=None):
+    """Run 1 warm-up + `nt` steps of {local half under try/except; MIN-agree on success; collective half}.  Returns
+    (error or None, timed steps completed, perf_counter at the start of the timed steps).  Every rank executes the same sequence
+    of collectives whatever fails locally (FCVSR_BENCH_TRAIN_FAIL_RANK=r: test hook, rank r's local half raises at step 1)."""
+    fail_rank = os.environ.get("FCVSR_BENCH_TRAIN_FAIL_RANK")
+    done, t1 = 0, None
+    for it in range(nt + 1):                                                # iteration 0 = warm-up (allocations, capture)
+        ok = err is None
+        if ok:
+            try:
+                if fail_rank is not None and int(fail_rank) == rank and it == 1:
+                    raise RuntimeError("FCVSR_BENCH_TRAIN_FAIL_RANK test hook")
+                local_fn(it)
+            except Exception as e:
+                ok, err = False, repr(e)[:300]
+        if not all_ranks_ok(ok, world, dev, backend):
+            err = err or "another rank failed"
+            break
+        collective_fn()
+        if it == 0:
+            after_warmup_fn()
+            t1 = time.perf_counter()
+        else:
+            done += 1
+    return err, done, t1
+
+
+def train_record(args, A, dev, world, rank, sd):
+    """BASELINE config 3 (sub-record, every rank takes part): FCVSR-S training step - batch 32 clips sharded 8 x 4 (here: 4
+    clips of 7x128x128 -> 512x512 per rank, the reference's RandomCrop(128), train_LD_freqCVSR_S_22.py:187), Charbonnier-sum
+    loss, Adam, ONE flat-buffer gradient all-reduce per step over RCCL.  Never part of `value`.
+
+    Failure is COLLECTIVE: the local half of every step (set-up, forward, backward) runs under try/except and the ranks agree
+    on a MIN-reduced ok flag before anybody enters the gradient all-reduce; one failing rank makes every rank skip the rest
+    with the same number of collectives behind it, and the headline line is still printed."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from fcvsr_amd.arch.schema import state_dict_shapes
+    from fcvsr_amd.weights import synthetic_state_dict
+    err = None
+    step = tx = th = None
+    try:
+        from fcvsr_amd.train import TrainStep
+        tm = A.GShiftNet_S()
+        tm.load_state_dict(synthetic_state_dict(state_dict_shapes("GShiftNet_S"), gain=0.5), strict=True)
+        tm = tm.to(dev)
+        tm.train_precision = args.train_precision
+        g = torch.Generator().manual_seed(300 + rank)                       # different data per rank, same weights
+        tx = torch.rand(4, 7, 1, 128, 128, generator=g).to(dev)
+        th = torch.rand(4, 1, 512, 512, generator=g).to(dev)
+        step = TrainStep(tm, lr=1e-4, weight_decay=1e-5, use_graph=bool(args.train_graph))
+    except Exception as e:
+        err = repr(e)[:300]
+    nt = 3
+    state = {"lv": float("nan")}
+
+    def local(it):
+        loss = step.local_backward(tx, th)
+        state["lv"] = float(loss.detach())                                  # host sync: the local half is complete
+
+    def after_warmup():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    err, done, t1 = guarded_steps(local, lambda: step.reduce_and_update(), after_warmup, nt, world, rank, dev, args.backend, err)
+    lv, sec = state["lv"], float("nan")
+    if err is None:
+        torch.cuda.synchronize()
+        tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev if world > 1 and args.backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        sec = float(tt) / nt
+    if err is not None:
+        log(f"train sub-record failed on some rank: {err}")
+        return {"error": err, "steps_done": done}
+    # the collective of the step, timed alone (same flat buffer, HIP events on the current stream)
+    ar_ms = None
+    try:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        step.allreduce()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(3):
+            step.allreduce()
+        e1.record()
+        torch.cuda.synchronize()
+        ar_ms = round(e0.elapsed_time(e1) / 3, 3)
+    except Exception as e:
+        log(f"all-reduce timing skipped: {e!r}")
+    # gradients of the timed (16-bit) mode against the exact-f32 mode on the same clips and weights (rank 0's shard)
+    grad_err = None
+    if rank == 0 and args.train_precision != "f32":
+        try:
+            def flat_grads(precision, graph):
+                m = A.GShiftNet_S()
+                m.load_state_dict(synthetic_state_dict(state_dict_shapes("GShiftNet_S"), gain=0.5), strict=True)
+                m = m.to(dev)
+                m.train_precision = precision
+                st = TrainStep(m, use_graph=graph)
+                st.local_backward(tx[:2], th[:2])
+                torch.cuda.synchronize()
+                return [p.grad.detach().double().reshape(-1).clone() for p in st.allreduce.params], st.names
+            g16, names = flat_grads(args.train_precision, bool(args.train_graph))
+            g32, _ = flat_grads("f32", False)
+            a16, a32 = torch.cat(g16), torch.cat(g32)
+            per = [float((u - v).abs().max() / v.abs().max().clamp_min(1e-30)) for u, v in zip(g16, g32)]
+            worst = int(np.argmax(per))
+            grad_err = {"rel_l2_all": float((a16 - a32).norm() / a32.norm()),
+                        "max_over_tensors_of_maxabs_over_tensor_max": per[worst], "worst_tensor": names[worst],
+                        "clips": 2, "vs": "exact-f32 training mode, same clips and weights"}
+        except Exception as e:
+            grad_err = {"error": repr(e)[:200]}
+    train = {"workload": "FCVSR-S training step: 4 clips of 7x128x128 -> 512x512 per GPU, Charbonnier-sum, Adam, "
+                         "flat f32 gradient all-reduce (SUM)", "world": world, "global_batch": 4 * world,
+             "conv_precision": args.train_precision + (" forward / input-gradient / weight-gradient on MFMA (f32 accumulate)" if args.train_precision != "f32" else " (exact)"),
+             "ms_per_step": round(sec * 1e3, 2), "clips_per_s": round(4 * world / sec, 2),
+             "allreduce_bytes": int(step.allreduce.numel * 4), "allreduce_ms": ar_ms, "finite_loss": bool(np.isfinite(lv)),
+             "hipgraph": bool(args.train_graph), "grad_rel_err_vs_f32": grad_err}
+    log(f"train sub-record: {train}")
+    return train
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,10 +326,12 @@ def main():
                          "(metric 'stub'); used by tests/test_dist_cpu.py with --backend gloo")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        if not args.stub and args.device is None:
-            import torch                                   # device_count() does not initialise the GPU
-            have = torch.cuda.device_count()
-            if have < args.gpus:
+        # The launcher parent imports nothing that could open /dev/kfd (no torch, no HIP): a process that has initialised the
+        # GPU must not fork + exec on this pool.  Devices are counted from the environment / sysfs; when neither can tell, the
+        # children validate their own ordinal (LOCAL_RANK < device_count()) and the first failure stops the rest.
+        if args.device is None and (not args.stub or "FCVSR_KFD_TOPOLOGY" in os.environ):   # a stub rehearsal needs no GPU
+            have = visible_gpu_count()
+            if have is not None and have < args.gpus:
                 raise SystemExit(f"--gpus {args.gpus} but only {have} HIP device(s) are visible "
                                  f"(rehearse N ranks on one GPU with --device 0)")
         sys.exit(self_launch(args.gpus))
@@ -168,6 +348,9 @@ def main():
     if args.stub:
         return stub_run(args, world, rank)
     local = local if args.device is None else args.device
+    if local >= torch.cuda.device_count():
+        log(f"rank {rank}: device ordinal {local} but only {torch.cuda.device_count()} HIP device(s) are visible")
+        sys.exit(4)                                       # the launcher stops the other ranks (self_launch / torchrun)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -211,8 +394,13 @@ def main():
             y = model(x)
         barrier()
         dt = time.perf_counter() - t0
+    per_rank_dt = [dt]
     if world > 1:
-        t = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        cdev = dev if args.backend == "nccl" else "cpu"
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)                              # every rank's own time: per-GPU fps in the line
+        per_rank_dt = [float(v.item()) for v in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert bool(torch.isfinite(y).all())
@@ -350,39 +538,7 @@ def main():
     # Adam, ONE flat-buffer gradient all-reduce per step over RCCL.  Never part of `value`.
     train = None
     if not args.no_train and not args.stub:
-        try:
-            from fcvsr_amd.train import TrainStep
-            tm = A.GShiftNet_S()
-            tm.load_state_dict(synthetic_state_dict(state_dict_shapes("GShiftNet_S"), gain=0.5), strict=True)
-            tm = tm.to(dev)
-            tm.train_precision = args.train_precision
-            g = torch.Generator().manual_seed(300 + rank)                       # different data per rank, same weights
-            tx = torch.rand(4, 7, 1, 128, 128, generator=g).to(dev)
-            th = torch.rand(4, 1, 512, 512, generator=g).to(dev)
-            step = TrainStep(tm, lr=1e-4, weight_decay=1e-5, use_graph=bool(args.train_graph))
-            step(tx, th)                                                         # warm-up (allocations, weight packing)
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            t1 = time.perf_counter()
-            nt = 3
-            for _ in range(nt):
-                lv = step(tx, th)
-            torch.cuda.synchronize()
-            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev if world > 1 and args.backend == "nccl" else "cpu")
-            if world > 1:
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            sec = float(tt) / nt
-            train = {"workload": "FCVSR-S training step: 4 clips of 7x128x128 -> 512x512 per GPU, Charbonnier-sum, Adam, "
-                                 "flat f32 gradient all-reduce (SUM)", "world": world, "global_batch": 4 * world,
-                     "conv_precision": args.train_precision + (" forward / input-gradient / weight-gradient on MFMA (f32 accumulate)" if args.train_precision != "f32" else " (exact)"),
-                     "ms_per_step": round(sec * 1e3, 2), "clips_per_s": round(4 * world / sec, 2),
-                     "allreduce_bytes": int(step.allreduce.numel * 4), "finite_loss": bool(np.isfinite(lv)), "hipgraph": bool(args.train_graph)}
-            log(f"train sub-record: {train}")
-            del tm, step, tx, th
-        except Exception as e:                                                   # a sub-record must never cost the headline line
-            train = {"error": repr(e)[:300]}
-            log(f"train sub-record failed: {e!r}")
+        train = train_record(args, A, dev, world, rank, sd)
 
     if rank == 0:
         line = {
@@ -395,6 +551,10 @@ def main():
                        "parallelism": f"clip-dp{world}"},
             "frames_per_sec_per_gpu": round(fps / world, 3),
             "conv_tflops_end_to_end": round(fps * conv_flops_live(args.model, H, W) / 1e12, 3),
+            "per_gpu_fps": [round(B * args.steps / t_r, 3) for t_r in per_rank_dt],
+            "dist": {"world": world, "backend": (dist.get_backend() if world > 1 else None),
+                     "rccl_world": (dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else None)},
+            "build": build_info(),
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "extras": extras, "train": train,
         }
         print(json.dumps(line))

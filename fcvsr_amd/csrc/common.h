@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include "../../include/fcvsr_hip.h"
 
 namespace fcvsr {
@@ -51,5 +52,28 @@ inline bool vec4_ok(const fcvsr_view& v) {
 }
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Per-DEVICE run-once guard for per-kernel attributes (hipFuncSetAttribute applies to the current device's copy of the
+// function) and other lazily created per-device state.  Thread-safe: the streamed harness and torch's autograd worker thread
+// may both enter the library.  One library-wide mutex (core.hip) serialises the first use on a device.
+struct DevOnce { unsigned char done[64]; };
+std::mutex& device_mutex();
+int device_cu_count(int dev);          // multiProcessorCount of `dev`, cached per device; 0 on error
+template <class F>
+inline hipError_t once_per_device(DevOnce& f, F fn, int* dev_out = nullptr) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (dev_out) *dev_out = dev;
+  if (__atomic_load_n(&f.done[dev], __ATOMIC_ACQUIRE)) return hipSuccess;
+  std::lock_guard<std::mutex> lock(device_mutex());
+  if (!f.done[dev]) {
+    e = fn();
+    if (e != hipSuccess) return e;
+    __atomic_store_n(&f.done[dev], (unsigned char)1, __ATOMIC_RELEASE);
+  }
+  return hipSuccess;
+}
 
 }  // namespace fcvsr

@@ -1136,13 +1136,11 @@ static hipError_t launch_lean(const MfmaArgs& a, int total_tiles, hipStream_t st
   size_t lds = ((size_t)6 * (kTW + 2) * kLD + (size_t)NT * kLD) * sizeof(uint16_t);
   const size_t epi = (4ull * 32 + 4) * ((NT >= 64 ? 64 : 32) + 4) * sizeof(float);
   if (lds < epi) lds = epi;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3_lean_kernel<BF16, NT, SRC16, DST16>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static DevOnce attr;
+  hipError_t e = once_per_device(attr, [&] {
+    return hipFuncSetAttribute((const void*)conv3_lean_kernel<BF16, NT, SRC16, DST16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL((conv3_lean_kernel<BF16, NT, SRC16, DST16>), dim3(total_tiles * a.n_nblk), dim3(256), lds, st, a);
   return hipGetLastError();
 }
@@ -1167,13 +1165,11 @@ static hipError_t launch_mfma(const MfmaArgs& a, int total_tiles, hipStream_t st
   size_t lds = ((size_t)(kTH + 2 * PAD) * (kTW + 2 * PAD) * kLD + (size_t)NT * kLD) * sizeof(uint16_t);
   const size_t epi = (4ull * 32 + 4) * ((NT >= 64 ? 64 : 32) + 4) * sizeof(float);   // epilogue transpose + GC partial areas
   if (lds < epi) lds = epi;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_mfma_kernel<BF16, NT, KS, MW, WD>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static DevOnce attr;
+  hipError_t e = once_per_device(attr, [&] {
+    return hipFuncSetAttribute((const void*)conv_mfma_kernel<BF16, NT, KS, MW, WD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL((conv_mfma_kernel<BF16, NT, KS, MW, WD>), dim3(total_tiles * a.n_nblk), dim3(256), lds, st, a);
   return hipGetLastError();
 }

@@ -441,18 +441,15 @@ bool conv3_res_supports(int cin, int cout) { return (cin == 64 && cout % 64 == 0
 
 template <bool BF16, int MODE, int NCH, int NSU>
 static hipError_t launch_res(const ResArgs& a, hipStream_t st) {
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    hipDeviceProp_t prop;
-    e = hipGetDeviceProperties(&prop, dev);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)conv3_res_kernel<BF16, MODE, NCH, NSU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRLds);
-    if (e != hipSuccess) return e;
-    n_cu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
-  }
+  static DevOnce attr;
+  int dev = 0;
+  hipError_t e = once_per_device(attr, [&] {
+    return hipFuncSetAttribute((const void*)conv3_res_kernel<BF16, MODE, NCH, NSU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRLds);
+  }, &dev);
+  if (e != hipSuccess) return e;
+  const int cus = device_cu_count(dev);
+  if (cus <= 0) return hipErrorInvalidDevice;
+  const int n_cu = cus > 8 ? cus / 8 * 8 : 8;
   const int NB = a.cout / (64 / NCH);
   // one persistent workgroup per CU; the grid is a multiple of 8 * NB (every XCD gets whole slots of NB cout blocks)
   int grid = n_cu / (8 * NB) * (8 * NB);

@@ -11,6 +11,20 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+std::mutex& device_mutex() {
+  static std::mutex mu;
+  return mu;
+}
+int device_cu_count(int dev) {
+  static int n_cu[64] = {0};
+  if (dev < 0 || dev >= 64) return 0;
+  int v = __atomic_load_n(&n_cu[dev], __ATOMIC_ACQUIRE);
+  if (v) return v;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  __atomic_store_n(&n_cu[dev], prop.multiProcessorCount, __ATOMIC_RELEASE);
+  return prop.multiProcessorCount;
+}
 }  // namespace fcvsr
 
 extern "C" const char* fcvsr_last_error(void) { return fcvsr::g_err; }

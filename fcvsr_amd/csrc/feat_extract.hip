@@ -161,16 +161,18 @@ extern "C" int fcvsr_feat_extract(const fcvsr_view* x, int B, int H, int W, cons
     a.dst[i] = dst[s]; a.dsx[i] = dst_pix_stride[s]; a.dch[i] = dst_ch_off[s];
   }
   const size_t lds = (size_t)kFePix * kFeLD * 2 + 4ull * 32 * kFeERow * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)feat_extract_kernel<true, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)feat_extract_kernel<false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static DevOnce attr;
+  {
+    hipError_t e = once_per_device(attr, [&] {
+      hipError_t e1 = hipFuncSetAttribute((const void*)feat_extract_kernel<true, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e1 == hipSuccess)
+        e1 = hipFuncSetAttribute((const void*)feat_extract_kernel<false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      return e1;
+    });
     if (e != hipSuccess) {
       set_error("fcvsr_feat_extract: %s", hipGetErrorString(e));
       return (int)e;
     }
-    attr_done = true;
   }
   const long long npix = (long long)B * H * W;
   dim3 grid(cdiv(npix, kFePix));

@@ -235,14 +235,15 @@ extern "C" int fcvsr_freq_mlp3(const float* const* xa, const float* const* xb, i
   a.sx = src_pix_stride; a.dsx = dst_pix_stride; a.npix = (int)npix; a.n_groups = n_dirs;
   a.tiles_per_group = cdiv(npix, kFmPix);
   a.w0 = (const uint16_t*)w0; a.w2 = (const uint16_t*)w2; a.w4 = (const uint16_t*)w4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)freq_mlp3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFmLds);
+  static DevOnce attr;
+  {
+    hipError_t e = once_per_device(attr, [&] {
+      return hipFuncSetAttribute((const void*)freq_mlp3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFmLds);
+    });
     if (e != hipSuccess) {
       set_error("fcvsr_freq_mlp3: %s", hipGetErrorString(e));
       return (int)e;
     }
-    attr_done = true;
   }
   hipLaunchKernelGGL(freq_mlp3_kernel, dim3(a.tiles_per_group * n_dirs), dim3(256), kFmLds, (hipStream_t)stream, a);
   FCVSR_LAUNCH_CHECK();

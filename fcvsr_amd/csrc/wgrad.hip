@@ -331,12 +331,11 @@ extern "C" int fcvsr_conv2d_wgrad_mfma(const fcvsr_view* x, const fcvsr_view* gy
   const dim3 grid(a.n_slabs, (a.cin / 64) * (a.cout / 64));
   if (kh == 3) {
     const size_t ldsb = 64 * kGyPitch + 3 * 64 * ((kGTY + 2) * kGTX * 2 + 16);
-    static bool attr3 = false;
-    if (!attr3) {
-      hipError_t e = hipFuncSetAttribute((const void*)wgrad_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-      if (e != hipSuccess) { set_error("fcvsr_conv2d_wgrad_mfma: %s", hipGetErrorString(e)); return (int)e; }
-      attr3 = true;
-    }
+    static DevOnce attr3;
+    hipError_t e = once_per_device(attr3, [&] {
+      return hipFuncSetAttribute((const void*)wgrad_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    });
+    if (e != hipSuccess) { set_error("fcvsr_conv2d_wgrad_mfma: %s", hipGetErrorString(e)); return (int)e; }
     hipLaunchKernelGGL(wgrad_mfma_kernel<3>, grid, dim3(256), ldsb, st, a, tiles_x, tiles_y, per_slab);
   } else {
     const size_t ldsb = 64 * kGyPitch + 64 * (kGTY * kGTX * 2 + 16);

@@ -95,17 +95,26 @@ class TrainStep:
         self.loss_fn = loss_fn
         self.allreduce = FlatGradAllReduce(params, reduce_op, group)
 
-    def __call__(self, lr_frames: torch.Tensor, hr: torch.Tensor) -> float:
-        """lr_frames: (b, 7, C, h, w), hr: (b, C, 4h, 4w) - this rank's share of the batch."""
+    def local_backward(self, lr_frames: torch.Tensor, hr: torch.Tensor) -> torch.Tensor:
+        """This rank's forward + loss + backward (no collective): gradients end up in `.grad`.  Split from the collective
+        half so that a caller can agree on success across ranks BEFORE anybody enters the all-reduce (bench.py does)."""
         if self.use_graph and lr_frames.is_cuda:
-            loss = self._graphed(lr_frames, hr)
-        else:
-            self.optimizer.zero_grad(set_to_none=True)
-            sr = self.model(lr_frames)
-            loss = self.loss_fn(sr, hr)
-            loss.backward()
+            return self._graphed(lr_frames, hr)
+        self.optimizer.zero_grad(set_to_none=True)
+        sr = self.model(lr_frames)
+        loss = self.loss_fn(sr, hr)
+        loss.backward()
+        return loss
+
+    def reduce_and_update(self) -> None:
+        """The collective half: ONE all-reduce of the flat gradient buffer, then the (replicated) optimizer step."""
         self.allreduce()
         self.optimizer.step()
+
+    def __call__(self, lr_frames: torch.Tensor, hr: torch.Tensor) -> float:
+        """lr_frames: (b, 7, C, h, w), hr: (b, C, 4h, 4w) - this rank's share of the batch."""
+        loss = self.local_backward(lr_frames, hr)
+        self.reduce_and_update()
         return float(loss.detach())
 
     def _graphed(self, lr_frames: torch.Tensor, hr: torch.Tensor) -> torch.Tensor:

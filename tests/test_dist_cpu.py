@@ -106,3 +106,91 @@ def test_bench_self_launch_stops_all_ranks_when_one_dies():
     assert p.returncode != 0
     assert time.time() - t0 < 120, "the surviving rank was left waiting"
     assert "rank 1 exited with code 3" in p.stderr
+
+
+def _bench_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def test_bench_launcher_parent_never_imports_torch(tmp_path):
+    """The `--gpus N` launcher parent (no RANK in its environment) must not import torch at all - torch.cuda.device_count() can
+    fall back to a HIP runtime call, and a process that has initialised the GPU must not fork + exec on this pool.  A
+    sitecustomize on PYTHONPATH records any torch import made by a process WITHOUT `RANK` and makes device_count() raise there."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    marker = tmp_path / "parent_imported_torch"
+    (tmp_path / "sitecustomize.py").write_text(
+        "import os, sys\n"
+        "if 'RANK' not in os.environ:\n"
+        "    class _F:\n"
+        "        def find_spec(self, name, path=None, target=None):\n"
+        "            if name == 'torch' or name.startswith('torch.'):\n"
+        f"                open({str(marker)!r}, 'a').write(name + '\\n')\n"
+        "                raise ImportError('launcher parent imported ' + name)\n"
+        "            return None\n"
+        "    sys.meta_path.insert(0, _F())\n")
+    env = dict(_bench_env(), PYTHONPATH=str(tmp_path) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    # a fake KFD topology with 2 GPU nodes and one CPU node: the parent counts devices from it (no *_VISIBLE_DEVICES set)
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        env.pop(k, None)
+    topo = tmp_path / "nodes"
+    for i, simd in enumerate((0, 1024, 1024)):
+        (topo / str(i)).mkdir(parents=True)
+        (topo / str(i) / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\n")
+    env["FCVSR_KFD_TOPOLOGY"] = str(topo)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub",
+                        "--steps", "2", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert not marker.exists(), marker.read_text()
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+    # 3 ranks on a 2-GPU topology: refused by the parent, still without torch
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--backend", "gloo", "--stub"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "only 2 HIP device" in p.stderr
+    assert not marker.exists()
+
+
+def test_bench_visible_gpu_count_sources(tmp_path, monkeypatch):
+    import importlib.util
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("FCVSR_KFD_TOPOLOGY", str(tmp_path / "absent"))
+    assert bench.visible_gpu_count() is None                 # no driver: the children validate their ordinals
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,3,5")
+    assert bench.visible_gpu_count() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count() == 0
+
+
+def test_bench_train_block_failure_is_collective():
+    """One rank whose LOCAL half of a training step raises must not leave the others inside the gradient all-reduce: the ranks
+    agree on a MIN-reduced ok flag before every collective, all of them skip the rest, rank 0 still prints the headline line
+    (with the error in `train`) and every rank exits 0 promptly (bench.py train block)."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    for fail in ("1", "0"):
+        env = dict(_bench_env(), FCVSR_BENCH_TRAIN_FAIL_RANK=fail)
+        t0 = time.time()
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub",
+                            "--steps", "2", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert time.time() - t0 < 120
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        rec = json.loads(lines[0])
+        assert "error" in rec["train"] and rec["train"]["steps_done"] == 0
+    # and without the hook the protocol completes its 3 timed steps
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub",
+                        "--steps", "2", "--warmup", "0"], env=_bench_env(), capture_output=True, text=True, timeout=300)
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["train"] == {"steps_done": 3, "world": 2}

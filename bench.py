@@ -522,6 +522,7 @@ def main():
             extras["f32_max_abs_vs_oracle"] = float((yf.cpu() - ref0).abs().max())
         model.precision, model.streams = args.precision, args.streams
         del yf
+        fm = None
         if args.model == "S":
             # the full model (BASELINE configs 2 / 4) with the same settings
             log("extras: full model")
@@ -530,7 +531,37 @@ def main():
             fm = fm.to(dev)
             fm.precision, fm.streams, fm.use_graph, fm.trunk16 = args.precision, args.streams, bool(args.graph), bool(args.trunk16)
             extras["full_model_fps"] = round(B / timeit(fm, x, 1, 3), 2)
-            del fm
+        # BASELINE config 5 as a number: REDS4-shaped sequences (4 x 100 LR frames of 180x320, anna_file/REDS4_GT.txt) streamed
+        # from PINNED HOST memory through the harness scheduler - every LR frame uploaded once, windows gathered on the device,
+        # uint8 SR frames copied back to pinned host memory: the PCIe legs are INSIDE this number (they never are in `value`)
+        if (H, W) == (180, 320):
+            try:
+                from fcvsr_amd.harness.infer import StreamedSuperResolver
+                gs = torch.Generator().manual_seed(55)
+                seqs = [torch.rand(100, 1, H, W, generator=gs).pin_memory() for _ in range(4)]
+                stream = {"workload": "4 sequences x 100 LR frames 180x320 in pinned host memory -> uint8 720x1280 frames in pinned host "
+                                      "memory, replicate-padded 7-frame windows, batch %d" % B}
+                for name, mdl, resident in (("S", model, fps), ("full", fm, extras.get("full_model_fps"))):
+                    if mdl is None:
+                        continue
+                    ssr = StreamedSuperResolver(mdl, batch=B)
+                    ssr.run(seqs)                                     # warm-up: buffers page-locked, hipGraph captured
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    out = ssr.run(seqs)
+                    sec = time.perf_counter() - t1
+                    assert sum(v[1].shape[0] for v in out.values()) == 400
+                    stream[name] = {"fps": round(400 / sec, 2), "resident_input_fps": resident,
+                                    "ratio": round(400 / sec / resident, 4) if resident else None,
+                                    "h2d_bytes_per_frame": ssr.stats["h2d_bytes"] // 400, "d2h_bytes_per_frame": ssr.stats["d2h_bytes"] // 400,
+                                    "frames_uploaded": ssr.stats["frames_uploaded"]}
+                    del ssr
+                extras["stream"] = stream
+                extras["stream_fps"] = stream.get("S", {}).get("fps")
+                del seqs
+            except Exception as e:
+                extras["stream"] = {"error": repr(e)[:300]}
+        del fm
         log(f"extras: {extras}")
 
     # BASELINE config 3 (sub-record, every rank takes part): FCVSR-S training step - batch 32 clips sharded 8 x 4 (here: 4 clips

@@ -1468,6 +1468,7 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
     wa.w = a.w; wa.bias = a.bias; wa.act = a.act; wa.slope = a.slope; wa.slope_ptr = a.slope_ptr;
     wa.rs[0] = a.rs[0]; wa.rs[1] = a.rs[1]; wa.n_res = a.n_res; wa.res16 = a.res16; wa.ps = a.ps; wa.zeros = zeros;
     { const char* wd_ = getenv("FCVSR_RES_DBG"); wa.dbg = wd_ ? atoi(wd_) : 0; }
+    { const char* wv_ = getenv("FCVSR_RES_V"); wa.variant = wv_ ? atoi(wv_) : 1; }
     wa.stamps = nullptr;
     {
       const char* ws_ = getenv("FCVSR_RES_STAMPS");       // diagnostic: in-kernel cycle stamps of one workgroup (scripts/res_stamps.py)
@@ -1477,7 +1478,7 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
         wa.stamps = (unsigned long long*)g_res_stamps;
       }
     }
-    FCVSR_NOTE_KERNEL("conv3_res_kernel<%s, %d, %d, %d>", tf(mma_dtype == FCVSR_BF16), !a.dst16 ? 0 : (a.n_res == 0 ? 2 : 1), cin / 64,
+    FCVSR_NOTE_KERNEL((wa.variant >= 3 && mma_dtype == FCVSR_BF16 && a.dst16 && a.n_res == 0) ? "conv3_res3_kernel<%s, %d, %d, %d>" : "conv3_res_kernel<%s, %d, %d, %d>", tf(mma_dtype == FCVSR_BF16), !a.dst16 ? 0 : (a.n_res == 0 ? 2 : 1), cin / 64,
                       a.act == FCVSR_ACT_NONE ? 2 : ((a.act == FCVSR_ACT_RELU || (a.act == FCVSR_ACT_LEAKY && a.slope >= 0.f && a.slope <= 1.f)) ? 1 : 0));
     e = launch_conv3_res(wa, mma_dtype == FCVSR_BF16, a.dst16 != 0, st);
     if (e != hipSuccess) {

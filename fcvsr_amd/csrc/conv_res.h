@@ -26,6 +26,7 @@ struct ResArgs {
   int n_res, res16;
   int ps;                 // PixelShuffle(2) store (cin 64, cout % 256 == 0, rows packed sub-pixel-major): cout block nb is sub-pixel nb / (cout/256)
   const void* zeros;      // >= 16 zero bytes: source of the halo pixels that lie outside the image
+  int variant;            // 1: conv3_res_kernel (round 2), 3: conv3_res3_kernel (three wave groups: copy / multiply / store) where it applies
   int dbg;                // profiling ablations (FCVSR_RES_DBG): 1 skip staging, 2 skip MFMA, 4 skip stores
   unsigned long long* stamps;   // diagnostic (FCVSR_RES_STAMPS=1): s_memtime stamps of workgroup 0, [wave 8][phase 64][slot 8]; else nullptr
 };

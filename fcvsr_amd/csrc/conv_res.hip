@@ -437,6 +437,207 @@ __global__ __launch_bounds__(512, 2) void conv3_res_kernel(ResK a) {
   }
 }
 
+
+// =====================================================================================================================
+// conv3_res3_kernel (round 3): THREE wave groups (768 threads, three waves per SIMD) rotate through three roles, one phase each:
+//   copy    : LDS-DMA of the unit's 10 x 34 halo tile into buffer (p + 1) & 1, wait for it (the only role that waits on memory);
+//   multiply: the 144 MFMAs per wave of the unit from buffer p & 1 - nothing else, so the SIMD's matrix pipe has a multiplying
+//             wave from barrier to barrier;
+//   store   : bias + activation + 16-bit packing of the finished tile and its stores.
+// In conv3_res_kernel (two groups, two roles) the multiplying role also carried the epilogue arithmetic (1.4 k of its 8.5 k cycles,
+// matrix pipe idle) because the other role was full with copy + stores (round-2 stamps; moving the arithmetic
+// into the copy / store role, interleaved with the LDS-DMA pieces, measured 10-29 % SLOWER: profiles/NOTES.md).  With the third
+// group the phase is the multiply loop alone.  Two halo buffers still suffice: the buffer being filled in phase p is the one read in
+// phase p + 1, the one read in phase p is free again in phase p + 1.  16-bit destination without residuals only (the accumulators
+// are packed in place); the other destinations stay on conv3_res_kernel.
+// The weight rows are staged in a PERMUTED output-channel order (LDS row 8g + 4h + e of a 32-row block holds output channel
+// 16h + 4g + e): the 16 accumulator registers of a lane are 16 CONSECUTIVE output channels of its pixel, so the store role needs no
+// v_permlane32_swap and a lane's two 16-byte stores are adjacent.  Same products, same summation order: bit-identical results.
+template <bool BF16, int NCH, int NSU, int PF>
+__global__ __launch_bounds__(768, 3) void conv3_res3_kernel(ResK a) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  constexpr int CO = 64 / NCH;                       // couts per workgroup
+  constexpr int MF = CO / 32;                        // weight (A operand) fragments per wave
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wq = wave & 3;          // role group 0..2, row pair inside the tile
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+
+  const int NB = a.cout / CO;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int nb = loc % NB, slot = loc / NB, nslots = (gridDim.x >> 3) / NB;
+  const int tb = (int)((long long)xcd * a.total_tiles / 8), te = (int)((long long)(xcd + 1) * a.total_tiles / 8);
+  const int n0 = nb * CO;
+  const int ntile = (tb + slot < te) ? (te - tb - slot + nslots - 1) / nslots : 0;     // tiles of this workgroup
+  if (ntile == 0) return;                                                               // uniform per workgroup
+  const int nmine = ntile > grp ? (ntile - grp + 2) / 3 : 0;                            // my tiles: list indices grp, grp + 3, ...
+  const int TMAX = (ntile + 2) / 3;                                                     // tiles of group 0 (the most)
+
+  // ---- resident weights, output channels permuted inside every block of 32 rows ----------------------------------------
+  {
+    const int sub = lane >> 3, cl = lane & 7;
+#pragma unroll
+    for (int i = 0; i < kRWRows / 8 / 12; ++i) {
+      const int g = wave + 12 * i;
+      const int row = g * 8 + sub;
+      const int q = row / CO, co = row - q * CO;
+      const int ch = q / 9, tap = q - ch * 9;
+      const int c = cl ^ ((co >> 1) & 7);
+      const int co_src = (co & ~31) | (((co >> 2) & 1) << 4) | (((co >> 3) & 3) << 2) | (co & 3);
+      const uint16_t* src = a.w + ((long long)tap * a.cout_pad + n0 + co_src) * a.cin_pad + ch * 64 + c * 8;
+      glds16(src, __builtin_amdgcn_readfirstlane(lds0 + g * 1024));
+    }
+  }
+  if (tid < CO) reinterpret_cast<float*>(lds + kRBiasOff)[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
+  if (tid >= 128 && tid < 128 + 96) reinterpret_cast<int*>(lds + kRTabOff)[tid - 128] = a.tab[(tid - 128) >> 5][(tid - 128) & 31];
+  const int* tabL = reinterpret_cast<const int*>(lds + kRTabOff);
+
+  float ns = 1.f;
+  if (a.act == FCVSR_ACT_RELU) ns = 0.f;
+  else if (a.act == FCVSR_ACT_LEAKY) ns = a.slope;
+  else if (a.act == FCVSR_ACT_PRELU) ns = *reinterpret_cast<const __attribute__((address_space(1))) float*>(reinterpret_cast<uintptr_t>(a.slope_ptr));
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                   // weights, bias and the parameter table are in LDS
+
+  // Group g runs {copy, multiply, store} of its unit in phases g + 3u, g + 3u + 1, g + 3u + 2 (u = unit number): every phase has
+  // exactly one copying, one multiplying and one storing group.  The three roles of a unit are straight-line code inside ONE loop
+  // iteration, so the accumulators are defined and consumed within an iteration - no loop-carried register tuple for hipcc to
+  // shuffle between roles.  Every wave executes the same number of s_barrier instructions: grp + 3 * NCH * TMAX + (2 - grp).
+  for (int i = 0; i < grp; ++i) __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+  for (int ti = 0; ti < TMAX; ++ti) {
+    const bool act = ti < nmine;
+    // Everything derived from the lane id is recomputed per tile (a few VALU instructions) instead of living in registers across the
+    // roles: at three waves per SIMD a wave has 168 registers, and the multiply loop needs 64 accumulators + 48 fragment registers +
+    // ~24 LDS address bases.  The empty asm makes the lane id opaque, so hipcc cannot hoist what depends on it.
+    int lv = lane, z0 = 0;
+    asm volatile("" : "+v"(lv), "+s"(z0));
+    const int r = lv & 31, h = lv >> 5;
+    const int* tabP = tabL + z0;                     // (same for the parameter table: its LDS reads land in VGPRs)
+    const int tile = tb + slot + (3 * ti + grp) * nslots;
+    f32x16_t acc[MF][2];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int p0 = grp + 3 * (ti * NCH + ch);      // phase of this unit's copy; its multiply runs in phase p0 + 1
+      const unsigned bsel = ((p0 + 1) & 1) * kRXBytes;
+      // ================= copy the unit's halo tile into the buffer the next phase multiplies from =========================
+      if (act) {
+        if (!(a.dbg & 1)) {
+          if (!(a.dbg & 16)) __builtin_amdgcn_s_setprio(1);
+          const ResTile t = res_decode(tabP, a.n_groups, tile);
+          res_stage(tabP, a.zeros, t, ch, lds0 + kRWBytes + bsel, wq, lv);
+          __builtin_amdgcn_s_setprio(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      // ================= multiply ==========================================================================================
+      if (act) {
+        if (ch == 0) {
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int i = 0; i < 16; ++i) acc[mf][j][i] = 0.f;
+        }
+        if (!(a.dbg & 2)) {
+          if (a.dbg & 64) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
+          const unsigned wch = ch * (9 * CO * 128);
+          const unsigned xsel = kRWBytes + bsel;
+          unsigned wb[4], xb[3][4];                  // fragment addresses relative to lds
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            wb[kk] = wch + r * 128 + (((2 * kk + h) ^ ((r >> 1) & 7)) << 4);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+              xb[kx][kk] = xsel + (2 * wq * kRHW + r + kx) * 128 + (((2 * kk + h) ^ (((r + kx) >> 1) & 7)) << 4);
+          }
+          uint4 wf[PF][MF], xf[PF][2];              // fragments are read PF - 1 steps ahead of their MFMAs
+#define FCVSR_RES_LOAD(S, SLOT)                                                                                  \
+  do {                                                                                                           \
+    constexpr int tap_ = (S) / 4, kk_ = (S) % 4, ky_ = tap_ / 3, kx_ = tap_ % 3;                                 \
+    _Pragma("unroll") for (int mf = 0; mf < MF; ++mf)                                                            \
+        wf[SLOT][mf] = *reinterpret_cast<const uint4*>(lds + wb[kk_] + (tap_ * CO + mf * 32) * 128);             \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
+        xf[SLOT][j] = *reinterpret_cast<const uint4*>(lds + xb[kx_][kk_] + (j + ky_) * kRRowB);                   \
+  } while (0)
+#define FCVSR_RES_STEP(S)                                                                                        \
+  do {                                                                                                           \
+    if ((S) + PF - 1 < 36) FCVSR_RES_LOAD(((S) + PF - 1) % 36, ((S) + PF - 1) % PF);                             \
+    _Pragma("unroll") for (int mf = 0; mf < MF; ++mf)                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+            acc[mf][j] = mfma<BF16>(wf[(S) % PF][mf], xf[(S) % PF][j], acc[mf][j]);                               \
+    if ((S) + PF - 1 < 36) __builtin_amdgcn_sched_group_barrier(0x100, MF + 2, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF, 0);                                                      \
+  } while (0)
+          FCVSR_RES_LOAD(0, 0);
+          FCVSR_RES_LOAD(1, 1);
+          if (PF > 3) FCVSR_RES_LOAD(2, 2);
+          __builtin_amdgcn_sched_barrier(0);
+          FCVSR_RES_STEP(0);  FCVSR_RES_STEP(1);  FCVSR_RES_STEP(2);  FCVSR_RES_STEP(3);  FCVSR_RES_STEP(4);  FCVSR_RES_STEP(5);
+          FCVSR_RES_STEP(6);  FCVSR_RES_STEP(7);  FCVSR_RES_STEP(8);  FCVSR_RES_STEP(9);  FCVSR_RES_STEP(10); FCVSR_RES_STEP(11);
+          FCVSR_RES_STEP(12); FCVSR_RES_STEP(13); FCVSR_RES_STEP(14); FCVSR_RES_STEP(15); FCVSR_RES_STEP(16); FCVSR_RES_STEP(17);
+          FCVSR_RES_STEP(18); FCVSR_RES_STEP(19); FCVSR_RES_STEP(20); FCVSR_RES_STEP(21); FCVSR_RES_STEP(22); FCVSR_RES_STEP(23);
+          FCVSR_RES_STEP(24); FCVSR_RES_STEP(25); FCVSR_RES_STEP(26); FCVSR_RES_STEP(27); FCVSR_RES_STEP(28); FCVSR_RES_STEP(29);
+          FCVSR_RES_STEP(30); FCVSR_RES_STEP(31); FCVSR_RES_STEP(32); FCVSR_RES_STEP(33); FCVSR_RES_STEP(34); FCVSR_RES_STEP(35);
+#undef FCVSR_RES_STEP
+#undef FCVSR_RES_LOAD
+          __builtin_amdgcn_s_setprio(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS reads are complete before the next phase's copy overwrites
+      }
+      __builtin_amdgcn_s_barrier();
+      // ================= epilogue + stores of the finished tile ===============================================================
+      if (act && ch == NCH - 1 && !(a.dbg & 8)) {
+        if (a.dbg & 32) __builtin_amdgcn_s_setprio(1);
+        const ResTile t = res_decode(tabP, a.n_groups, tile);
+        const int* T = tabP + t.gi * 32;
+        const int GH = T[kTH], GW = T[kTW];
+        gchar_t* dbase = tab_ptr(T, kTDstLo);
+        const int px = t.tx0 + r;
+        const float* bias_a = reinterpret_cast<const float*>(lds + kRBiasOff) + 16 * h;   // my 16 consecutive couts of each 32-block
+        // PixelShuffle(2): rows are packed sub-pixel-major, so this workgroup's 64 couts are 64 consecutive channels of ONE
+        // sub-pixel (i, j): the same store at pixel (2y + i, 2x + j), channel n0 % (cout/4)
+        const int cq4 = a.cout >> 2, sp = a.ps ? n0 / cq4 : 0, nch = a.ps ? n0 - sp * cq4 : n0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // registers 4g..4g+3 of fragment (mf, j) = couts mf*32 + 16h + 4g + [0, 4) of pixel r: + bias, activation, packed into
+          // registers 2g, 2g+1; registers 0..7 then hold the lane's 16 consecutive couts = two adjacent 16-byte stores
+          uint2 pk[MF][4];
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float4 b4 = *reinterpret_cast<const float4*>(bias_a + mf * 32 + 4 * g);
+              float v[4] = {acc[mf][j][4 * g] + b4.x, acc[mf][j][4 * g + 1] + b4.y, acc[mf][j][4 * g + 2] + b4.z,
+                            acc[mf][j][4 * g + 3] + b4.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (NSU != 2) v[e] = NSU == 1 ? fmaxf(v[e], ns * v[e]) : fmaxf(v[e], 0.f) + ns * fminf(v[e], 0.f);
+              pk[mf][g] = cvt4<BF16>(make_float4(v[0], v[1], v[2], v[3]));
+            }
+          const int py = t.ty0 + 2 * wq + j;
+          const bool ok = (py < GH) && (px < GW) && !(a.dbg & 4);
+          const int pyc = ok ? py : 0, pxc = ok ? px : 0;
+          const int dyy = a.ps ? 2 * pyc + (sp >> 1) : pyc, dxx = a.ps ? 2 * pxc + (sp & 1) : pxc;
+          const unsigned dpix = (unsigned)(t.b * T[kTDstSb] + dyy * T[kTDstSy] + dxx * T[kTDstSx] + nch + 16 * h);   // elements
+          if (ok) {
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+              for (int q = 0; q < 2; ++q)
+                gstore(dbase + (size_t)(dpix + mf * 32 + 8 * q) * 2, make_uint4(pk[mf][2 * q].x, pk[mf][2 * q].y, pk[mf][2 * q + 1].x, pk[mf][2 * q + 1].y));
+          }
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  for (int i = 0; i < 2 - grp; ++i) __builtin_amdgcn_s_barrier();
+}
+
 bool conv3_res_supports(int cin, int cout) { return (cin == 64 && cout % 64 == 0) || (cin == 128 && cout % 32 == 0); }
 
 template <bool BF16, int MODE, int NCH, int NSU>
@@ -444,7 +645,11 @@ static hipError_t launch_res(const ResArgs& a, hipStream_t st) {
   static DevOnce attr;
   int dev = 0;
   hipError_t e = once_per_device(attr, [&] {
-    return hipFuncSetAttribute((const void*)conv3_res_kernel<BF16, MODE, NCH, NSU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRLds);
+    hipError_t e1 = hipFuncSetAttribute((const void*)conv3_res_kernel<BF16, MODE, NCH, NSU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRLds);
+    if constexpr (BF16 && MODE == 2)
+      if (e1 == hipSuccess)
+        e1 = hipFuncSetAttribute((const void*)conv3_res3_kernel<true, NCH, NSU, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRLds);
+    return e1;
   }, &dev);
   if (e != hipSuccess) return e;
   const int cus = device_cu_count(dev);
@@ -475,7 +680,14 @@ static hipError_t launch_res(const ResArgs& a, hipStream_t st) {
     put(kTR0Lo, r0.p); T[kTR0Sb] = (int)r0.sb; T[kTR0Sy] = (int)r0.sy; T[kTR0Sx] = (int)r0.sx;
     put(kTR1Lo, r1.p); T[kTR1Sb] = (int)r1.sb; T[kTR1Sy] = (int)r1.sy; T[kTR1Sx] = (int)r1.sx;
   }
-  hipLaunchKernelGGL((conv3_res_kernel<BF16, MODE, NCH, NSU>), dim3(grid), dim3(512), kRLds, st, k);
+  bool v2 = false;
+  if constexpr (BF16 && MODE == 2) {     // 16-bit destination without residuals: the three-group kernel
+    if (a.variant == 3) {
+      hipLaunchKernelGGL((conv3_res3_kernel<true, NCH, NSU, 3>), dim3(grid), dim3(768), kRLds, st, k);
+      v2 = true;
+    }
+  }
+  if (!v2) hipLaunchKernelGGL((conv3_res_kernel<BF16, MODE, NCH, NSU>), dim3(grid), dim3(512), kRLds, st, k);
   return hipGetLastError();
 }
 

@@ -65,18 +65,21 @@ class StreamedSuperResolver:
     CVSR_train/test_LD_freqCVSR_S_22.py:66-91 with the sequence list of anna_file/REDS4_GT.txt).
 
     * this rank's share of the flattened frame list comes from `harness.sharding.shard_sequences` (contiguous ranges; no
-      data-path collective), so a rank reads only its ranges plus a 3-frame halo;
-    * frames stay on the host (pinned); each batch of windows is gathered on the host, copied on a side stream while the
-      previous batch is in the model (double buffering: two pinned staging buffers, two device buffers, two events), and the
-      quantised SR frames come back into a preallocated pinned uint8 buffer - the 288 GB of HBM are not needed for the
-      sequences themselves, only two batches are resident;
+      data-path collective), so a rank reads only its ranges plus the window halo;
+    * frames stay on the host (pinned).  EVERY LR FRAME IS UPLOADED ONCE: new frames of the next batch go through a pinned
+      staging buffer into a ring of device frame slots on a side stream while the current batch is in the model, and the
+      windows are built ON THE DEVICE by an index gather from that ring (consecutive windows share 6 of their 7 frames: the
+      round-2 version re-uploaded all 7, 1.6 MB per window instead of 0.23 MB); the quantised SR frames come back into a
+      preallocated pinned uint8 buffer.  Only the ring and two batches are resident in HBM;
     * the last, partial batch is padded to the full batch size so that every call has the same shape (one hipGraph / one
       set of cached buffers in the engine), padded outputs are dropped.
+    `stats` (after run): frames uploaded, H2D / D2H bytes.
     """
 
     def __init__(self, model, *, num_frames: int = 7, padding: str = "replicate", batch: int = 8, quantise: str = "truncate"):
         self.model, self.num_frames, self.padding, self.batch, self.quantise = model, num_frames, padding, batch, quantise
         self.device = next(model.parameters()).device
+        self.stats = {}
 
     def plan(self, seq_lens, rank: int = 0, world: int = 1):
         """[(seq, centre)] of this rank, in order."""
@@ -87,6 +90,7 @@ class StreamedSuperResolver:
     def run(self, sequences, rank: int = 0, world: int = 1):
         """sequences: list of (N_s, C, H, W) float tensors in [0,1] (host; all of one frame size).
         Returns {seq: (first_centre, uint8 array (n, C, 4H, 4W))} for the frames this rank owns."""
+        from .sharding import shard_sequences
         seq_lens = [int(s.shape[0]) for s in sequences]
         work = self.plan(seq_lens, rank, world)
         if not work:
@@ -95,47 +99,95 @@ class StreamedSuperResolver:
         for s in sequences:
             if tuple(s.shape[1:]) != (C, H, W):
                 raise ValueError("all sequences of one run must share the frame size")
-        padded = [pad_to_multiple(s.float(), 4) for s in sequences]
-        Hp, Wp = padded[0].shape[-2:]
+        ph, pw = (-H) % 4, (-W) % 4
+        Hp, Wp = H + ph, W + pw
         B, T = self.batch, self.num_frames
         on_gpu = self.device.type == "cuda"
         pin = dict(pin_memory=True) if on_gpu else {}
-        stage = [torch.empty((B, T, C, Hp, Wp), dtype=torch.float32, **pin) for _ in range(2)]
-        dev_in = [torch.empty((B, T, C, Hp, Wp), dtype=torch.float32, device=self.device) for _ in range(2)]
-        out_host = torch.empty((len(work), C, 4 * H, 4 * W), dtype=torch.uint8, **pin)
+        batches = [work[i:i + B] for i in range(0, len(work), B)]
+        # window frame lists per batch (the last batch is padded with its own last window) and the frames each batch adds
+        win_idx = []
+        for items in batches:
+            rows = []
+            for k in range(B):
+                s, c = items[min(k, len(items) - 1)]
+                rows.append([(s, j) for j in window_indices(c, T, seq_lens[s], self.padding)])
+            win_idx.append(rows)
+        need = [sorted({f for row in rows for f in row}) for rows in win_idx]
+        max_new = max(len(n) for n in need)
+        ring_n = 2 * max(len(a) + len(b) for a, b in zip(need, need[1:] + [[]])) + max_new      # > two consecutive batches' frames
+        # buffers (pinned staging, device ring, pinned output) are kept across runs of the same geometry: page-locking a few
+        # hundred MB costs more than streaming a sequence
+        key = (ring_n, max_new, len(work), C, H, W, B, T, str(self.device))
+        if getattr(self, "_buf_key", None) != key:
+            self._bufs = dict(
+                ring=torch.zeros((ring_n, C, Hp, Wp), dtype=torch.float32, device=self.device),   # zero padding rows / columns stay zero
+                stage=[torch.zeros((max_new, C, Hp, Wp), dtype=torch.float32, **pin) for _ in range(2)],
+                slot_stage=[torch.zeros((max_new,), dtype=torch.int64, **pin) for _ in range(2)],
+                gidx_stage=[torch.zeros((B * T,), dtype=torch.int64, **pin) for _ in range(2)],
+                gidx_dev=[torch.zeros((B * T,), dtype=torch.int64, device=self.device) for _ in range(2)],
+                out_host=torch.empty((len(work), C, 4 * H, 4 * W), dtype=torch.uint8, **pin))
+            self._buf_key = key
+        ring, stage, slot_stage = self._bufs["ring"], self._bufs["stage"], self._bufs["slot_stage"]
+        gidx_stage, gidx_dev, out_host = self._bufs["gidx_stage"], self._bufs["gidx_dev"], self._bufs["out_host"]
         copy_stream = torch.cuda.Stream(self.device) if on_gpu else None
         ready = [torch.cuda.Event() for _ in range(2)] if on_gpu else None
-        consumed = [torch.cuda.Event() for _ in range(2)] if on_gpu else None
-        batches = [work[i:i + B] for i in range(0, len(work), B)]
+        gathered = [torch.cuda.Event() for _ in range(2)] if on_gpu else None
+        where = {}                                                   # (seq, frame) -> ring slot; owner[slot] = its frame
+        owner = [None] * ring_n
+        head = 0
+        up_frames = 0
 
         def fill(bi):
-            buf = stage[bi & 1]
-            for k in range(B):
-                s, c = batches[bi][min(k, len(batches[bi]) - 1)]          # pad the last batch with its own last window
-                idx = window_indices(c, T, seq_lens[s], self.padding)
-                for t, j in enumerate(idx):
-                    buf[k, t].copy_(padded[s][j])
+            """Host side of batch bi: stage its NEW frames, upload them into free ring slots, upload its gather indices."""
+            nonlocal head, up_frames
+            buf, sl, gi = stage[bi & 1], slot_stage[bi & 1], gidx_stage[bi & 1]
+            keep = set(need[bi]) | (set(need[bi - 1]) if bi >= 1 else set())     # batch bi-1 may still be gathering
+            new = [f for f in need[bi] if f not in where]
+            slots = []
+            for f in new:
+                while owner[head] is not None and owner[head] in keep:
+                    head = (head + 1) % ring_n
+                if owner[head] is not None:
+                    del where[owner[head]]
+                owner[head], where[f] = f, head
+                slots.append(head)
+                head = (head + 1) % ring_n
+            for q, (s, j) in enumerate(new):
+                buf[q, :, :H, :W].copy_(sequences[s][j])
+            up_frames += len(new)
+            for k, row in enumerate(win_idx[bi]):
+                for t, f in enumerate(row):
+                    gi[k * T + t] = where[f]
+            n = len(new)
+            if n:
+                sl[:n] = torch.tensor(slots, dtype=torch.int64)
             if on_gpu:
                 with torch.cuda.stream(copy_stream):
-                    if bi >= 2:
-                        copy_stream.wait_event(consumed[bi & 1])          # the model has read this device buffer
-                    dev_in[bi & 1].copy_(buf, non_blocking=True)
+                    if bi >= 1:
+                        copy_stream.wait_event(gathered[(bi - 1) & 1])   # slots it overwrites were last read by a gather <= bi-2
+                    if n:
+                        ring.index_copy_(0, sl[:n].to(self.device, non_blocking=True), buf[:n].to(self.device, non_blocking=True))
+                    gidx_dev[bi & 1].copy_(gi, non_blocking=True)
                     ready[bi & 1].record(copy_stream)
             else:
-                dev_in[bi & 1].copy_(buf)
+                if n:
+                    ring.index_copy_(0, sl[:n], buf[:n])
+                gidx_dev[bi & 1].copy_(gi)
 
         fill(0)
         pos = 0
         for bi, items in enumerate(batches):
             if on_gpu:
                 torch.cuda.current_stream(self.device).wait_event(ready[bi & 1])
+            win = ring.index_select(0, gidx_dev[bi & 1]).reshape(B, T, C, Hp, Wp)
+            if on_gpu:
+                gathered[bi & 1].record(torch.cuda.current_stream(self.device))
             if bi + 1 < len(batches):
                 if on_gpu and bi >= 1:
-                    ready[(bi + 1) & 1].synchronize()                     # host staging buffer of batch bi-1 has been copied
-                fill(bi + 1)                                              # overlaps the model call below
-            sr = self.model(dev_in[bi & 1])[:, :, :4 * H, :4 * W]
-            if on_gpu:
-                consumed[bi & 1].record(torch.cuda.current_stream(self.device))
+                    ready[(bi + 1) & 1].synchronize()                     # staging buffers of batch bi-1 have been consumed
+                fill(bi + 1)                                              # host work + upload overlap the model call below
+            sr = self.model(win)[:, :, :4 * H, :4 * W]
             sr = sr.clamp(0, 1) * 255.0
             sr = sr.round() if self.quantise == "round" else sr
             n = len(items)
@@ -143,8 +195,10 @@ class StreamedSuperResolver:
             pos += n
         if on_gpu:
             torch.cuda.synchronize(self.device)
+        self.stats = {"frames_uploaded": up_frames, "windows": len(work), "h2d_bytes": up_frames * C * Hp * Wp * 4,
+                      "d2h_bytes": len(work) * C * 16 * H * W, "ring_slots": ring_n}
         res, arr, k = {}, out_host.numpy(), 0
-        for (s, a, b) in __import__("fcvsr_amd.harness.sharding", fromlist=["shard_sequences"]).shard_sequences(seq_lens, rank, world):
+        for (s, a, b) in shard_sequences(seq_lens, rank, world):
             res[s] = (a, arr[k:k + (b - a)].copy())
             k += b - a
         return res

@@ -118,9 +118,24 @@ SIGNATURES = {
     "fcvsr_bilinear_up4": [_PV, _I, _I, _I, _PV, _VP],
     "fcvsr_tail_fused": [_PV, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _PV, _VP],
     "fcvsr_conv_last": [_PV, _VP, _VP, _I, _I, _I, _I, _PV, _VP],
+    "fcvsr_pack_weight_mfma": [_VP, _I, _I, _I, _I, _VP, _I, _I, _I, _I, _VP],
+    "fcvsr_act_bwd": [_VP, _VP, _VP, _F, C.c_longlong, _VP],
+    "fcvsr_colsum_scratch_elems": [C.c_longlong, _I],
+    "fcvsr_colsum": [_VP, C.c_longlong, _I, _VP, _VP, C.c_longlong, _VP],
+    "fcvsr_iac_bwd_sac": [_VP, _VP, _VP, _VP, _PV, _F, _I, _I, _I, _I, _VP, _I, _VP, _PV, _I, _VP],
+    "fcvsr_iac_bwd_warp": [_VP, _PV, _VP, _PV, _I, _I, _I, _I, _VP, _VP, _VP],
+    "fcvsr_prelu_fwd": [_VP, _VP, _VP, C.c_longlong, _VP],
+    "fcvsr_prelu_bwd": [_VP, _VP, _VP, _VP, _VP, _VP, C.c_longlong, _VP],
+    "fcvsr_wgrad_cout1_scratch_elems": [_I, _I, _I],
+    "fcvsr_wgrad_cout1": [_VP, _VP, _I, _I, _I, _I, _VP, _VP, C.c_longlong, _VP],
+    "fcvsr_rcbt_nblk": [_I],
+    "fcvsr_rcbt_stat_elems": [],
+    "fcvsr_rcbt_forward": [_VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, C.c_longlong, _VP],
+    "fcvsr_rcbt_backward": [_VP, _VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, C.c_longlong, _VP],
 }
 _RESTYPES = {"fcvsr_last_error": C.c_char_p, "fcvsr_last_conv_kernel": C.c_char_p, "fcvsr_conv2d_wgrad_scratch_elems": C.c_longlong,
-             "fcvsr_conv2d_wgrad_mfma_scratch_elems": C.c_longlong}
+             "fcvsr_conv2d_wgrad_mfma_scratch_elems": C.c_longlong, "fcvsr_colsum_scratch_elems": C.c_longlong,
+             "fcvsr_wgrad_cout1_scratch_elems": C.c_longlong}
 
 
 def lib() -> C.CDLL:

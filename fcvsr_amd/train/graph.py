@@ -19,24 +19,25 @@ import torch
 import torch.nn.functional as F
 
 from ..engine import band_masks_half
+from .blocks import iac_both, prelu, rcb_tail
 from .ops import conv2d
 
 Tensor = torch.Tensor
 
 
 class _Ctx:
-    def __init__(self, p: Dict[str, Tensor], precision: str):
+    def __init__(self, p: Dict[str, Tensor], precision: str, fused_blocks: bool = True):
         self.p, self.precision = p, precision
+        self.fused_blocks = fused_blocks                # False: every non-convolution operator as torch ops (the test reference)
 
-    def conv(self, key: str, x: Tensor, stride: int = 1) -> Tensor:
-        return conv2d(x, self.p[key + ".weight"], self.p.get(key + ".bias"), stride, self.precision)
+    def conv(self, key: str, x: Tensor, stride: int = 1, act=None, slope: float = 0.0) -> Tensor:
+        """nn.Conv2d + optional LeakyReLU / ReLU evaluated in the HIP kernel's epilogue (one launch)."""
+        return conv2d(x, self.p[key + ".weight"], self.p.get(key + ".bias"), stride, self.precision, act, slope)
 
     def chain(self, key: str, t: Tensor, n: int) -> Tensor:
         """n bias-free 1x1 convolutions with ReLU in between (convfuse / convcrt / convcorr, CVSR_freq.py:1371-1396)."""
         for li in range(n):
-            t = conv2d(t, self.p[f"{key}.{2 * li}.weight"], None, 1, self.precision)
-            if li < n - 1:
-                t = F.relu(t)
+            t = conv2d(t, self.p[f"{key}.{2 * li}.weight"], None, 1, self.precision, "relu" if li < n - 1 else None)
         return t
 
     def ca(self, key: str, z: Tensor) -> Tensor:
@@ -48,15 +49,24 @@ class _Ctx:
 
 
 def _lrelu(x: Tensor, s: float) -> Tensor:
-    return torch.where(x >= 0, x, x * s)
+    return F.leaky_relu(x, s)                                       # one kernel each way (was a where / mul / compare chain)
 
 
 def _prelu(x: Tensor, a: Tensor) -> Tensor:
-    return torch.where(x >= 0, x, x * a.reshape(1, -1, 1, 1))
+    return prelu(x, a) if _FUSED_PRELU else F.prelu(x, a.reshape(-1))
+
+
+_FUSED_PRELU = True
 
 
 def _ps2(x: Tensor) -> Tensor:
-    return F.pixel_shuffle(x, 2)
+    """PixelShuffle(2) (out[c, 2h+i, 2w+j] = in[4c+2i+j, h, w]) on the NHWC buffer: ONE copy with contiguous channel runs whose result
+    is channels_last again.  F.pixel_shuffle returns an NCHW-contiguous tensor, which cost a 268 MB transposing copy (4.2 ms) in front
+    of the next convolution and another one in the backward."""
+    B, C4, H, W = x.shape
+    c = C4 // 4
+    xv = x.permute(0, 2, 3, 1).reshape(B, H, W, c, 2, 2)
+    return xv.permute(0, 1, 4, 2, 5, 3).reshape(B, 2 * H, 2 * W, c).permute(0, 3, 1, 2)
 
 
 def _spec(x: Tensor) -> Tensor:
@@ -115,7 +125,7 @@ def _sac(s: Tensor, k1: Tensor) -> Tensor:
 def _mgaa(c: _Ctx, key: str, x: Tensor, A: int) -> Tensor:
     B, C3, H, W = x.shape
     d = C3 // 3
-    x1, x2, x3 = x[:, :d], x[:, d:2 * d], x[:, 2 * d:]
+    x1, x2, x3 = torch.split(x, d, dim=1)                            # (one cat in the backward instead of three zero-filled slices)
     x1f, x2f, x3f = _spec(x1), _spec(x2), _spec(x3)
     off_f = (x1f - x2f) + c.chain(key + ".convfuse", torch.cat([x1f, x2f], 1), 3)
     off_b = (x3f - x2f) + c.chain(key + ".convfuse", torch.cat([x3f, x2f], 1), 3)
@@ -133,6 +143,9 @@ def _mgaa(c: _Ctx, key: str, x: Tensor, A: int) -> Tensor:
             o = (c.ca(blk + ".CA", u) + u) * sim
             dst.append(torch.fft.irfft2(torch.complex(o[:, :2].contiguous(), o[:, 2:].contiguous()), s=(H, W), norm="backward"))
     K = c.conv(key + ".F.1", c.conv(key + ".F.0", c.conv(key + ".conv_KP", x2)))
+    if c.fused_blocks and d in (32, 64):
+        a_f, a_b = iac_both(x1, x3, K, offs[0], offs[1], 0.1)
+        return c.conv(key + ".conv3", torch.cat([a_f, a_b], 1)) + x2
     al = []
     for feat_in, ofs in ((x1, offs[0]), (x3, offs[1])):
         feat = feat_in
@@ -176,18 +189,24 @@ def _mffr(c: _Ctx, key: str, x: Tensor, Q: int) -> Tensor:
 
 
 def _context_block(c: _Ctx, key: str, r: Tensor) -> Tensor:
+    """ContextBlock (:657-701): softmax-pooled context vector through a two-layer bottleneck, added to every pixel.  The two
+    reductions over channels / pixels are batched matrix products on the NHWC buffer (no conv wrapper, no (B,C,HW) product)."""
     B, C, H, W = r.shape
-    logits = conv2d(r, c.p[key + ".conv_mask.weight"], None, 1, "f32").reshape(B, 1, H * W)
-    m = torch.softmax(logits, dim=2)
-    ctx = (r.reshape(B, C, H * W) * m).sum(dim=2)
-    t = _lrelu(ctx @ c.p[key + ".channel_add_conv.0.weight"].flatten(1).t(), 0.2)
+    rm = r.permute(0, 2, 3, 1).reshape(B, H * W, C)                  # zero-copy view of the channels_last tensor
+    logits = rm @ c.p[key + ".conv_mask.weight"].reshape(C, 1)       # (B, HW, 1)
+    m = torch.softmax(logits, dim=1)
+    ctx = (m.transpose(1, 2) @ rm).reshape(B, C)                     # (B,1,HW) x (B,HW,C)
+    t = F.leaky_relu(ctx @ c.p[key + ".channel_add_conv.0.weight"].flatten(1).t(), 0.2)
     return r + (t @ c.p[key + ".channel_add_conv.2.weight"].flatten(1).t())[:, :, None, None]
 
 
 def _block_rcb(c: _Ctx, key: str, xs: List[Tensor]) -> List[Tensor]:
     def body(z):
-        z = c.conv(key + ".body.2", _lrelu(c.conv(key + ".body.0", z), 0.1))
-        r = c.conv(key + ".RCB.body.2", _lrelu(c.conv(key + ".RCB.body.0", z), 0.2))
+        z = c.conv(key + ".body.2", c.conv(key + ".body.0", z, act="lrelu", slope=0.1))
+        r = c.conv(key + ".RCB.body.2", c.conv(key + ".RCB.body.0", z, act="lrelu", slope=0.2))
+        if r.shape[1] == 64 and c.fused_blocks:
+            g = key + ".RCB.gcnet"
+            return rcb_tail(r, z, c.p[g + ".conv_mask.weight"], c.p[g + ".channel_add_conv.0.weight"], c.p[g + ".channel_add_conv.2.weight"], 0.2)
         return _lrelu(_context_block(c, key + ".RCB.gcnet", r), 0.2) + z
 
     def dn(z):
@@ -210,7 +229,7 @@ def _scnet(c: _Ctx, key: str, xs: List[Tensor], G: int) -> List[Tensor]:
     return [x + r for x, r in zip(xs, cur)]
 
 
-def forward_train(p: Dict[str, Tensor], x: Tensor, *, precision: str = "f32") -> Tensor:
+def forward_train(p: Dict[str, Tensor], x: Tensor, *, precision: str = "f32", fused_blocks: bool = True) -> Tensor:
     """x: (B,7,C,H,W) device tensor in [0,1] -> (B,C,4H,4W), differentiable w.r.t. every live parameter in `p`."""
     if not x.is_cuda:
         raise RuntimeError("fcvsr_amd.train needs device tensors (the HIP path has no CPU fallback)")
@@ -221,7 +240,7 @@ def forward_train(p: Dict[str, Tensor], x: Tensor, *, precision: str = "f32") ->
     B, T, C, H, W = x.shape
     if H % 4 or W % 4:
         raise ValueError("H and W must be multiples of 4 (3-level pyramid, reference BlockRCB :766-777)")
-    c = _Ctx(p, precision)
+    c = _Ctx(p, precision, fused_blocks)
     feat = conv2d(x.reshape(B, T * C, H, W).float(), p["feat_extract.0.weight"], p["feat_extract.0.bias"], 1, "f32")
     f1, f2, f3 = feat[:, :3 * n], feat[:, 3 * n:4 * n], feat[:, 4 * n:]
     a1 = _mgaa(c, "MGAA", f1, A)
@@ -238,8 +257,8 @@ def forward_train(p: Dict[str, Tensor], x: Tensor, *, precision: str = "f32") ->
     l2 = _prelu(c.conv("upconv1_L2", o1), a)
     l2 = _ps2(l2 + c.conv("upconv1_L2_2", torch.cat([l2, l3_1], 1)))
     fz = c.conv("recorb0", c.conv("upconv_fuse", torch.cat([o0, l2, l3_2], 1)))
-    u = _prelu(_ps2(c.conv("upconv1", fz)), a)
-    u = _prelu(_ps2(c.conv("upconv2", u)), a)
-    out = conv2d(u, p["conv_last0.weight"], p["conv_last0.bias"], 1, "f32")
+    u = _ps2(_prelu(c.conv("upconv1", fz), a))                      # PReLU (one shared slope) commutes with the shuffle: same values,
+    u = _ps2(_prelu(c.conv("upconv2", u), a))                       # and the activation then runs on the dense conv output
+    out = conv2d(u, p["conv_last0.weight"], p["conv_last0.bias"], 1, precision)   # (16-bit modes: a 4-channel MFMA layer, rows 1..3 zero)
     base = F.interpolate(x[:, T // 2].float(), scale_factor=4, mode="bilinear", align_corners=False)
     return out + base

@@ -5,20 +5,32 @@ CVSR_train/arch/CVSR_freq.py under `loss.backward()`, train_LD_freqCVSR_S_22.py:
 Tensors are (B,C,H,W) in torch's channels_last memory format, i.e. NHWC in memory, the layout of the HIP kernels: the
 (B,H,W,C) permutation handed to the C ABI is a zero-copy view.
 
-precision "f32": exact-f32 direct kernels in all directions (the mode the gradient goldens are checked in).
+precision "f32": exact-f32 kernels in all directions (the mode the gradient goldens are checked in).
 precision "bf16"/"f16": forward and input gradient on the matrix cores (fcvsr_conv2d_mfma, f32 accumulate) when the layer is
 eligible (1x1 / 3x3, channel counts the MFMA path takes); weight gradient with bf16 products on the matrix cores for the
 3x3 / 1x1 layers with multiples of 64 channels (fcvsr_conv2d_wgrad_mfma), exact f32 for the rest.
+
+Round 3: a layer is ONE forward launch and at most five backward launches.  Bias and LeakyReLU / ReLU ride in the forward
+kernel's epilogue (`act`, `slope`); the activation's backward is one elementwise launch on the saved OUTPUT; the bias gradient is
+a two-stage column sum; the 16-bit operand packings of the weight (forward and transposed + tap-flipped for the input
+gradient) are one launch each, cached per parameter version - they were chains of 4-8 small torch kernels per layer and step.
 """
 from __future__ import annotations
 
-from typing import Optional
+import ctypes as C
+from typing import Dict, Optional, Tuple
 
 import torch
 
 from .. import hip
 
 _MMA = {"bf16": (hip.BF16, torch.bfloat16), "f16": (hip.F16, torch.float16)}
+_ACT = {None: hip.ACT_NONE, "none": hip.ACT_NONE, "relu": hip.ACT_RELU, "lrelu": hip.ACT_LEAKY}
+
+# packed 16-bit weights per (storage pointer, parameter version, dtype, transposed): valid until the optimizer writes the
+# parameter (which bumps _version); bounded so that a long run cannot grow it
+_PACKED: Dict[Tuple, torch.Tensor] = {}
+_PACKED_MAX = 4096
 
 
 def _nhwc(t: torch.Tensor) -> torch.Tensor:
@@ -26,71 +38,130 @@ def _nhwc(t: torch.Tensor) -> torch.Tensor:
     return t.permute(0, 2, 3, 1).contiguous()           # no copy when t is already channels_last
 
 
-def _run_conv(x_nhwc: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stride: int, precision: str) -> torch.Tensor:
-    """x (B,H,W,Cin) f32, w (Cout,Cin,k,k) -> (B,Ho,Wo,Cout) f32 ("same" padding k//2)."""
+def packed_weight_mfma(w: torch.Tensor, tdt: torch.dtype, transposed: bool) -> torch.Tensor:
+    """16-bit operand layout of fcvsr_conv2d_mfma for `w` (or for the input-gradient convolution), one HIP launch, cached."""
+    key = (w.data_ptr(), w._version, tdt, transposed, tuple(w.shape), str(w.device))
+    got = _PACKED.get(key)
+    if got is not None:
+        return got
+    if len(_PACKED) >= _PACKED_MAX:
+        _PACKED.clear()
+    cout, cin, kh, kw = w.shape
+    rows, cols = (cin, cout) if transposed else (cout, cin)
+    rp, cp = (rows + 127) // 128 * 128, (cols + 63) // 64 * 64
+    out = torch.empty((kh * kw, rp, cp), dtype=tdt, device=w.device)
+    wd = w.detach()
+    if wd.dtype != torch.float32 or not wd.is_contiguous():
+        wd = wd.float().contiguous()
+    hip.check(hip.lib().fcvsr_pack_weight_mfma(wd.data_ptr(), cout, cin, kh, kw, out.data_ptr(), rp, cp, hip._DT[tdt], int(transposed),
+                                               hip.stream_ptr()), "fcvsr_pack_weight_mfma")
+    _PACKED[key] = out
+    return out
+
+
+def _run_conv(x_nhwc: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stride: int, precision: str, *,
+              transposed: bool = False, act: int = hip.ACT_NONE, slope: float = 0.0) -> torch.Tensor:
+    """x (B,H,W,Cin) f32, w (Cout,Cin,k,k) [transposed: the input-gradient convolution with w^T, taps flipped] -> (B,Ho,Wo,Cout) f32
+    ("same" padding k//2), bias and activation in the kernel's epilogue."""
     cout, cin, k, _ = w.shape
+    if transposed:
+        cout, cin = cin, cout
     B, H, W, _ = x_nhwc.shape
     pad = k // 2
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     out = torch.empty((B, Ho, Wo, cout), dtype=torch.float32, device=x_nhwc.device)
-    b = None if bias is None else bias.detach().float().contiguous()
-    if precision in _MMA and k in (1, 3) and stride == 1 and cin % 4 == 0 and cout % 4 == 0:
+    b = None if bias is None else bias.detach()
+    if b is not None and (b.dtype != torch.float32 or not b.is_contiguous()):
+        b = b.float().contiguous()
+    if precision in _MMA and k in (1, 3) and stride == 1 and cin % 4 == 0 and (cout % 4 == 0 or cout < 4):
         mdt, tdt = _MMA[precision]
-        groups = [dict(srcs=[x_nhwc], dst=out)]
+        co4, dst, b4 = cout, out, b
+        if cout < 4:             # conv_last0 (64 -> 1 at 4H x 4W): run as a 4-channel layer, the packed weight rows past cout are zero
+            co4 = 4
+            dst = torch.empty((B, Ho, Wo, 4), dtype=torch.float32, device=x_nhwc.device)
+            b4 = None if b is None else torch.nn.functional.pad(b, (0, 4 - cout))
+        groups = [dict(srcs=[x_nhwc], dst=dst)]
         if hip.mfma_eligible(k, stride, groups):
-            hip.conv2d_mfma(groups, hip.pack_conv_weight_mfma(w, tdt), k, cout, mdt, bias=b)
-            return out
-    wm = hip.pack_conv_weight_f32mfma(w) if (k in (1, 3) and stride == 1 and cin % 32 == 0 and cout % 4 == 0) else None
-    hip.conv2d([x_nhwc], hip.pack_conv_weight(w), k, cout, out, bias=b, stride=stride, w_f32mfma=wm)
+            hip.conv2d_mfma(groups, packed_weight_mfma(w, tdt, transposed), k, co4, mdt, bias=b4, act=act, slope=slope)
+            return dst if co4 == cout else dst[..., :cout]
+    wl = w.detach()
+    if transposed:
+        wl = wl.permute(1, 0, 2, 3).flip(2, 3).contiguous()
+    wm = hip.pack_conv_weight_f32mfma(wl) if (k in (1, 3) and stride == 1 and cin % 32 == 0 and cout % 4 == 0) else None
+    hip.conv2d([x_nhwc], hip.pack_conv_weight(wl), k, cout, out, bias=b, stride=stride, w_f32mfma=wm, act=act, slope=slope)
+    return out
+
+
+def _colsum(g_nhwc: torch.Tensor) -> torch.Tensor:
+    """Sum over (b, y, x) of a dense (B,H,W,C) f32 tensor: the bias gradient."""
+    Cn = g_nhwc.shape[3]
+    npix = g_nhwc.numel() // Cn
+    L = hip.lib()
+    n = L.fcvsr_colsum_scratch_elems(npix, Cn)
+    scratch = torch.empty(n, dtype=torch.float32, device=g_nhwc.device)
+    out = torch.empty(Cn, dtype=torch.float32, device=g_nhwc.device)
+    hip.check(L.fcvsr_colsum(g_nhwc.data_ptr(), npix, Cn, out.data_ptr(), scratch.data_ptr(), n, hip.stream_ptr()), "fcvsr_colsum")
     return out
 
 
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, precision):
+    def forward(ctx, x, w, bias, stride, precision, act, slope):
         xv = _nhwc(x.float())
-        ctx.save_for_backward(xv, w)
-        ctx.stride, ctx.precision, ctx.has_bias = stride, precision, bias is not None
-        out = _run_conv(xv, w.detach(), bias, stride, precision)
+        out = _run_conv(xv, w, bias, stride, precision, act=act, slope=slope)
+        ctx.save_for_backward(xv, w, out if act != hip.ACT_NONE else None)
+        ctx.stride, ctx.precision, ctx.has_bias, ctx.act, ctx.slope = stride, precision, bias is not None, act, slope
         return out.permute(0, 3, 1, 2)                    # (B,Cout,Ho,Wo), channels_last in memory
 
     @staticmethod
     def backward(ctx, gy):
-        xv, w = ctx.saved_tensors
+        xv, w, y = ctx.saved_tensors
         stride, precision = ctx.stride, ctx.precision
         cout, cin, k, _ = w.shape
         B, H, W, _ = xv.shape
         gyv = _nhwc(gy.float())
+        L = hip.lib()
+        if ctx.act != hip.ACT_NONE:                       # gradient at the pre-activation, from the saved output
+            gp = torch.empty_like(gyv)
+            hip.check(L.fcvsr_act_bwd(gyv.data_ptr(), y.data_ptr(), gp.data_ptr(), ctx.slope if ctx.act == hip.ACT_LEAKY else 0.0,
+                                      gyv.numel(), hip.stream_ptr()), "fcvsr_act_bwd")
+            gyv = gp
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             # dL/dx = "same" stride-1 convolution of dL/dy (zero-inserted for stride 2) with the transposed, tap-flipped weight
-            wt = w.detach().permute(1, 0, 2, 3).flip(2, 3).contiguous()
             g_in = gyv
             if stride != 1:
                 g_in = torch.zeros((B, H, W, cout), dtype=torch.float32, device=gyv.device)
                 g_in[:, ::stride, ::stride, :][:, :gyv.shape[1], :gyv.shape[2]] = gyv
-            gx = _run_conv(g_in, wt, None, 1, precision).permute(0, 3, 1, 2)
-        if ctx.needs_input_grad[1]:
-            L = hip.lib()
+            gx = _run_conv(g_in, w, None, 1, precision, transposed=True).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1] and cout == 1 and k == 3 and stride == 1 and cin in (16, 32, 64):
+            # one output channel (conv_last0): x is read once, 9 x cin accumulators per thread
+            n = L.fcvsr_wgrad_cout1_scratch_elems(B, H, cin)
+            scratch = torch.empty(n, dtype=torch.float32, device=xv.device)
+            gw = torch.empty((1, cin, 3, 3), dtype=torch.float32, device=xv.device)
+            hip.check(L.fcvsr_wgrad_cout1(xv.data_ptr(), gyv.data_ptr(), B, H, W, cin, gw.data_ptr(), scratch.data_ptr(), n, hip.stream_ptr()),
+                      "fcvsr_wgrad_cout1")
+        elif ctx.needs_input_grad[1]:
             Ho, Wo = gyv.shape[1], gyv.shape[2]
             # 16-bit modes: products on the matrix cores for the 3x3 / 1x1 layers with multiples of 64 channels; exact f32 otherwise
             mm = precision in _MMA and L.fcvsr_conv2d_wgrad_mfma_eligible(cin, cout, k, k, stride, k // 2)
             n = (L.fcvsr_conv2d_wgrad_mfma_scratch_elems if mm else L.fcvsr_conv2d_wgrad_scratch_elems)(B, Ho, Wo, cin, cout, k, k)
             scratch = torch.empty(n, dtype=torch.float32, device=xv.device)
             gw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=xv.device)
-            import ctypes as C
             xd, gd = hip.view(xv), hip.view(gyv)
             fn = L.fcvsr_conv2d_wgrad_mfma if mm else L.fcvsr_conv2d_wgrad
             hip.check(fn(C.addressof(xd), C.addressof(gd), B, H, W, k, k, stride, k // 2, gw.data_ptr(), scratch.data_ptr(), n,
                          hip.stream_ptr()), "fcvsr_conv2d_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gyv.sum(dim=(0, 1, 2))
-        return gx, gw, gb, None, None
+            gb = _colsum(gyv)
+        return gx, gw, gb, None, None, None, None
 
 
-def conv2d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, precision: str = "f32") -> torch.Tensor:
-    """nn.Conv2d(k, stride, padding=k//2) with HIP forward / input-gradient / weight-gradient kernels.  CUDA (HIP) tensors only:
-    there is no CPU fallback."""
+def conv2d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, precision: str = "f32",
+           act: Optional[str] = None, slope: float = 0.0) -> torch.Tensor:
+    """act(nn.Conv2d(k, stride, padding=k//2)(x)) with HIP forward / input-gradient / weight-gradient kernels; `act` in
+    {None, "relu", "lrelu"} (slope) is evaluated in the forward kernel's epilogue and differentiated from the saved output.
+    CUDA (HIP) tensors only: there is no CPU fallback."""
     if not x.is_cuda:
         raise RuntimeError("fcvsr_amd.train.conv2d needs device tensors (the HIP path has no CPU fallback)")
-    return _Conv2dFn.apply(x, w, bias, stride, precision)
+    return _Conv2dFn.apply(x, w, bias, stride, precision, _ACT[act], float(slope))

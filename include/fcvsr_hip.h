@@ -112,6 +112,48 @@ int fcvsr_conv2d_wgrad_mfma_eligible(int cin, int cout, int kh, int kw, int stri
 long long fcvsr_conv2d_wgrad_mfma_scratch_elems(int B, int Ho, int Wo, int cin, int cout, int kh, int kw);
 int fcvsr_conv2d_wgrad_mfma(const fcvsr_view* x, const fcvsr_view* gy, int B, int H, int W, int kh, int kw, int stride, int pad,
                             float* dw, float* scratch, long long scratch_elems, void* stream);
+/* Training-path helpers (reference: the per-layer work of `loss.backward()` + `optimizer.step()`, train_LD_freqCVSR_S_22.py:244-251).
+ * fcvsr_pack_weight_mfma: nn.Conv2d.weight (cout,cin,kh,kw) f32 -> the 16-bit operand layout of fcvsr_conv2d_mfma,
+ *   [kh*kw][rows_pad][cols_pad] zero padded; transposed = 0: rows = cout, cols = cin (forward); transposed = 1: rows = cin,
+ *   cols = cout, taps flipped (the input-gradient convolution).  One launch (the weights change every optimizer step).
+ * fcvsr_act_bwd: out = g * (y > 0 ? 1 : slope), y = the activation's output (LeakyReLU / ReLU backward), n % 4 == 0, out may alias g.
+ * fcvsr_colsum: out[c] = sum over the npix rows of a dense (npix, C) f32 matrix (bias gradient), deterministic two-stage. */
+int fcvsr_pack_weight_mfma(const float* w, int cout, int cin, int kh, int kw, void* dst, int rows_pad, int cols_pad, int dtype,
+                           int transposed, void* stream);
+int fcvsr_act_bwd(const float* g, const float* y, float* out, float slope, long long n, void* stream);
+long long fcvsr_colsum_scratch_elems(long long npix, int C);
+int fcvsr_colsum(const float* x, long long npix, int C, float* out, float* scratch, long long scratch_elems, void* stream);
+/* RCB tail with the ContextBlock under training (CVSR_freq.py:657-701 inside RCB.forward :705-725), dense (B, HW, 64) f32:
+ *   out = LeakyReLU_slope(r + add(r)) + z,  add = W2 . LeakyReLU_slope(W1 . ctx),  ctx = sum_p softmax_p(wmask . r[p]) r[p].
+ * forward: three launches; stats (B x fcvsr_rcbt_stat_elems() floats) is what the backward needs besides r;
+ *   scratch >= B * fcvsr_rcbt_nblk(HW) * 66 floats.
+ * backward: g = dL/dout -> gr = dL/dr (dL/dz = g), dwmask[64], dw1[64x64], dw2[64x64] (row-major like the 1x1 conv weights);
+ *   scratch >= B * nblk * 64 + B * 65 + 4 + 2 * B * 4096 floats.  Two-stage fixed-order reductions (bit-reproducible). */
+int fcvsr_rcbt_nblk(int HW);
+int fcvsr_rcbt_stat_elems(void);
+int fcvsr_rcbt_forward(const float* r, const float* z, const float* wmask, const float* w1, const float* w2, float slope, int B, int HW,
+                       int C, float* out, float* stats, float* scratch, long long scratch_elems, void* stream);
+int fcvsr_rcbt_backward(const float* r, const float* g, const float* wmask, const float* w1, const float* w2, const float* stats,
+                        float slope, int B, int HW, int C, float* gr, float* dwmask, float* dw1, float* dw2, float* scratch,
+                        long long scratch_elems, void* stream);
+/* PReLU with one shared slope (nn.PReLU(), CVSR_freq.py:2590 / ConvBlk :349), slope in device memory:
+ *   fcvsr_prelu_fwd: y = x > 0 ? x : slope[0] * x;   fcvsr_prelu_bwd: gx and gslope[0] (two-stage sum; scratch >= 2048 floats). */
+int fcvsr_prelu_fwd(const float* x, const float* slope, float* y, long long n, void* stream);
+int fcvsr_prelu_bwd(const float* g, const float* x, const float* slope, float* gx, float* gslope, float* scratch, long long n, void* stream);
+/* Weight gradient of a 3x3 "same" convolution with ONE output channel (conv_last0, :2607): x dense (B,H,W,C) f32, gy dense (B,H,W) f32,
+ * dw (1,C,3,3); C in {16, 32, 64}; x is read once; fixed summation order. */
+long long fcvsr_wgrad_cout1_scratch_elems(int B, int H, int C);
+int fcvsr_wgrad_cout1(const float* x, const float* gy, int B, int H, int W, int C, float* dw, float* scratch, long long scratch_elems, void* stream);
+/* Backward of one IAC iteration under training (CVSR_freq.py:1230-1250; forward = fcvsr_warp, fcvsr_sac_v, fcvsr_sac_h, which leave
+ * s = flow_warp(prev, off) and v = SAC_v(s) in memory).  All tensors f32 NHWC; gy, yout (the iteration's output), v, s, gfin, gv, prev,
+ * gprev dense (B,H,W,C); k1 / gk: views of the iteration's 3*C kernel channels inside the predictor output / its gradient.
+ *   fcvsr_iac_bwd_sac : gfin (+)= gy * lrelu'(yout);  gv = transposed horizontal pass;  gk (+)= both passes' kernel gradients
+ *   fcvsr_iac_bwd_warp: gs = transposed vertical pass of gv;  gprev += bilinear scatter of gs (float atomics: gprev must be zeroed);
+ *                       goff (B,H,W,2) = d/d(off) of the bilinear sample.  C in {32, 64}. */
+int fcvsr_iac_bwd_sac(const float* gy, const float* yout, const float* v, const float* s, const fcvsr_view* k1, float slope, int B, int H,
+                      int W, int C, float* gfin, int fin_accumulate, float* gv, const fcvsr_view* gk, int k_accumulate, void* stream);
+int fcvsr_iac_bwd_warp(const float* gv, const fcvsr_view* k1, const float* prev, const fcvsr_view* off, int B, int H, int W, int C,
+                       float* gprev_zeroed, float* goff, void* stream);
 /* Diagnostic (FCVSR_RES_STAMPS=1 in the environment): copies the in-kernel cycle stamps the last resident-weight convolution
  * launch recorded for one workgroup, [wave 8][phase 64][slot 8] uint64, to host memory.  Not part of the data path. */
 int fcvsr_debug_res_stamps(void* host_out, size_t bytes);

@@ -15,6 +15,12 @@ def main(path, out=None):
     for name, n, s, a, mn, mx in rows:
         short = name if len(name) <= 70 else name[:67] + "..."
         lines.append(f"{short:70s} {n:7d} {s/1e6:10.3f} {a/1e3:10.2f} {mn/1e3:9.2f} {mx/1e3:9.2f} {100*s/tot:6.2f}")
+    import os
+    if os.environ.get("LONG_NAMES"):
+        lines.append("")
+        lines.append("# full names of the 60 largest entries")
+        for name, n, s_, a, mn, mx in rows[:60]:
+            lines.append(f"{s_/1e6:10.3f} ms {n:6d}  {name[:400]}")
     text = "\n".join(lines)
     print(text)
     if out:

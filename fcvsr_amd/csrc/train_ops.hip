@@ -78,8 +78,15 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ p
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;       // 4 threads per column, fixed combination order
   __shared__ float sm[4][64];
   float s = 0.f;
-  if (c < C)
-    for (int b = q; b < nblk; b += 4) s += part[(long long)b * C + c];
+  if (c < C) {
+    int b = q;
+    for (; b + 12 < nblk; b += 16) {                             // four independent loads in flight, added in block order
+      const float p0 = part[(long long)b * C + c], p1 = part[(long long)(b + 4) * C + c], p2 = part[(long long)(b + 8) * C + c],
+                  p3 = part[(long long)(b + 12) * C + c];
+      s += p0; s += p1; s += p2; s += p3;
+    }
+    for (; b < nblk; b += 4) s += part[(long long)b * C + c];
+  }
   sm[q][threadIdx.x & 63] = s;
   __syncthreads();
   if (q == 0 && c < C) out[c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(256) void wgrad_cout1_kernel(const float* __restric
       }
     }
   }
-  __shared__ float sm[9 * 256 * 4 / 4];                                  // [slot][9][C] floats, C * nslot = 1024 -> 9216 floats
+  __shared__ float sm[9 * 1024];                                         // [slot][C][9] floats: C * nslot = C * 256 / (C / 4) = 1024
   float* mine = sm + ((long long)slot * 9) * C + cq * 36;               // [slot][ci][tap]: nn.Conv2d's (ci, ky, kx) order
   if (slot < nslot)
 #pragma unroll
@@ -258,6 +265,31 @@ extern "C" int fcvsr_wgrad_cout1(const float* x, const float* gy, int B, int H, 
   hipLaunchKernelGGL(wgrad_cout1_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, gy, B, H, W, C, rpb, scratch);
   // column sums of the (nb, C*9) partial matrix in block order = dw in nn.Conv2d's (1, C, 3, 3) layout
   hipLaunchKernelGGL(colsum_stage2, dim3((9 * C + 63) / 64), dim3(256), 0, (hipStream_t)stream, scratch, nb, 9 * C, dw);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}
+
+/* column sums over 1..3 dense (npix[g], C) matrices added together (the bias gradient of a layer applied to several pyramid levels):
+ * stage 1 per matrix into consecutive block ranges of one scratch buffer, ONE ordered stage 2 */
+extern "C" long long fcvsr_colsum_groups_scratch_elems(const long long* npix, int n_groups, int C) {
+  long long nblk = 0;
+  for (int g = 0; g < n_groups; ++g) { const int rpb = colsum_rows(npix[g]); nblk += (npix[g] + rpb - 1) / rpb; }
+  return (nblk > 0 ? nblk : 1) * C;
+}
+
+extern "C" int fcvsr_colsum_groups(const float* const* xs, const long long* npix, int n_groups, int C, float* out, float* scratch,
+                                   long long scratch_elems, void* stream) {
+  FCVSR_CHECK_ARG(xs && npix && out && scratch && n_groups >= 1 && n_groups <= 3 && C >= 1, "bad arguments");
+  long long blk0 = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    FCVSR_CHECK_ARG(xs[g] && npix[g] >= 1, "empty matrix");
+    const int rpb = colsum_rows(npix[g]);
+    const long long nblk = (npix[g] + rpb - 1) / rpb;
+    FCVSR_CHECK_ARG(scratch_elems >= (blk0 + nblk) * C, "scratch too small");
+    hipLaunchKernelGGL(colsum_stage1, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, xs[g], npix[g], C, rpb, scratch + blk0 * C);
+    blk0 += nblk;
+  }
+  hipLaunchKernelGGL(colsum_stage2, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, scratch, (int)blk0, C, out);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

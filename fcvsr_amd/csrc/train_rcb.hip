@@ -221,6 +221,58 @@ __global__ __launch_bounds__(256) void rcbt_rowsum_kernel(const float* __restric
   out[i] = s;
 }
 
+// Adjoint of the x2 bilinear up-sampling of fcvsr_xscale (align_corners = False, source index clamped at 0 and at the last row /
+// column): low-resolution pixel (Y, X) collects from the high-resolution rows 2Y-1 .. 2Y+2 with weights 0.25 / 0.75 / 0.75 / 0.25,
+// the clamped share of the first and last row staying on the edge pixel; same along x.  g: (B, 2H, 2W, C), out: (B, H, W, C), f32.
+__global__ __launch_bounds__(256) void up2_adjoint_kernel(const float4* __restrict__ g, float4* __restrict__ out, int B, int H, int W, int Cq) {
+  const long long total = (long long)B * H * W * Cq;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int cq = (int)(t % Cq);
+  const long long pg = t / Cq;
+  const int X = (int)(pg % W), Y = (int)((pg / W) % H), b = (int)(pg / ((long long)W * H));
+  const int H2 = 2 * H, W2 = 2 * W;
+  float wy[4], wx[4];
+  int iy[4], ix[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    iy[k] = 2 * Y - 1 + k; ix[k] = 2 * X - 1 + k;
+    wy[k] = (k == 0 || k == 3) ? 0.25f : 0.75f;
+    wx[k] = wy[k];
+  }
+  // edges: the up-sampling clamps its source index, so row 0 of the output reads low-res row 0 with weight 1 (and so does row 2H-1
+  // with low-res row H-1); rows outside [0, 2H) do not exist
+  if (Y == 0) { wy[0] = 0.f; wy[1] = 1.f; }
+  if (Y == H - 1) { wy[3] = 0.f; wy[2] = 1.f; }
+  if (X == 0) { wx[0] = 0.f; wx[1] = 1.f; }
+  if (X == W - 1) { wx[3] = 0.f; wx[2] = 1.f; }
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    if (wy[a] == 0.f) continue;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (wx[c] == 0.f) continue;
+      const float w = wy[a] * wx[c];
+      const float4 v = g[(((long long)b * H2 + iy[a]) * W2 + ix[c]) * Cq + cq];
+      acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+    }
+  }
+  out[t] = acc;
+}
+
+// Adjoint of the 2x2 mean: out (B, 2H, 2W, C)[i][j] = 0.25 * g (B, H, W, C)[i / 2][j / 2]
+__global__ __launch_bounds__(256) void pool2_adjoint_kernel(const float4* __restrict__ g, float4* __restrict__ out, int B, int H, int W, int Cq) {
+  const long long total = (long long)B * (2 * H) * (2 * W) * Cq;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int cq = (int)(t % Cq);
+  const long long pg = t / Cq;
+  const int j = (int)(pg % (2 * W)), i = (int)((pg / (2 * W)) % (2 * H)), b = (int)(pg / ((long long)4 * W * H));
+  const float4 v = g[(((long long)b * H + (i >> 1)) * W + (j >> 1)) * Cq + cq];
+  out[t] = make_float4(0.25f * v.x, 0.25f * v.y, 0.25f * v.z, 0.25f * v.w);
+}
+
 }  // namespace fcvsr
 
 using namespace fcvsr;
@@ -271,6 +323,26 @@ extern "C" int fcvsr_rcbt_backward(const float* r, const float* g, const float* 
   hipLaunchKernelGGL(rcbt_rowsum_kernel, dim3(1), dim3(256), 0, st, part, B * nblk, kTC, dwmask);
   hipLaunchKernelGGL(rcbt_rowsum_kernel, dim3(kTC * kTC / 256), dim3(256), 0, st, dw1b, B, kTC * kTC, dw1);
   hipLaunchKernelGGL(rcbt_rowsum_kernel, dim3(kTC * kTC / 256), dim3(256), 0, st, dw2b, B, kTC * kTC, dw2);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}
+
+/* g (B, 2H, 2W, C) -> out (B, H, W, C): adjoint of the x2 bilinear up-sampling inside fcvsr_xscale */
+extern "C" int fcvsr_up2_adjoint(const float* g, float* out, int B, int H, int W, int C, void* stream) {
+  FCVSR_CHECK_ARG(g && out && B > 0 && H > 0 && W > 0 && C % 4 == 0, "bad arguments");
+  FCVSR_CHECK_ARG(((uintptr_t)g % 16) == 0 && ((uintptr_t)out % 16) == 0, "16-byte aligned tensors");
+  const long long total = (long long)B * H * W * (C / 4);
+  hipLaunchKernelGGL(up2_adjoint_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)g, (float4*)out, B, H, W, C / 4);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}
+
+/* g (B, H, W, C) -> out (B, 2H, 2W, C): adjoint of the 2x2 mean inside fcvsr_xscale */
+extern "C" int fcvsr_pool2_adjoint(const float* g, float* out, int B, int H, int W, int C, void* stream) {
+  FCVSR_CHECK_ARG(g && out && B > 0 && H > 0 && W > 0 && C % 4 == 0, "bad arguments");
+  FCVSR_CHECK_ARG(((uintptr_t)g % 16) == 0 && ((uintptr_t)out % 16) == 0, "16-byte aligned tensors");
+  const long long total = (long long)B * 4 * H * W * (C / 4);
+  hipLaunchKernelGGL(pool2_adjoint_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)g, (float4*)out, B, H, W, C / 4);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

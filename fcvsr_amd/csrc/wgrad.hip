@@ -347,3 +347,63 @@ extern "C" int fcvsr_conv2d_wgrad_mfma(const fcvsr_view* x, const fcvsr_view* gy
   FCVSR_LAUNCH_CHECK();
   return 0;
 }
+
+// The same weight gradient summed over up to 3 problems that share the weight (the pyramid levels of a BlockRCB layer, reference
+// CVSR_freq.py:766-777: one nn.Conv2d applied to every level): one matrix-core launch per problem into consecutive slab ranges of
+// ONE scratch buffer, then ONE ordered reduction over all slabs (levels in order): no per-level gradient tensors, no additions.
+extern "C" long long fcvsr_conv2d_wgrad_mfma_groups_scratch_elems(const int* B, const int* H, const int* W, int n_groups, int cin, int cout,
+                                                                  int kh, int kw) {
+  long long slabs = 0;
+  for (int g = 0; g < n_groups; ++g) slabs += wgrad_mfma_slabs(B[g], H[g], W[g], cin, cout);
+  return slabs * kh * kw * cin * cout;
+}
+
+extern "C" int fcvsr_conv2d_wgrad_mfma_groups(const fcvsr_view* xs, const fcvsr_view* gys, const int* B, const int* H, const int* W, int n_groups,
+                                              int kh, int kw, int pad, float* dw, float* scratch, long long scratch_elems, void* stream) {
+  FCVSR_CHECK_ARG(xs && gys && B && H && W && dw && scratch, "null argument");
+  FCVSR_CHECK_ARG(n_groups >= 1 && n_groups <= 3, "1..3 problems");
+  const int cin = xs[0].c, cout = gys[0].c;
+  FCVSR_CHECK_ARG(fcvsr_conv2d_wgrad_mfma_eligible(cin, cout, kh, kw, 1, pad), "layer not eligible for the matrix-core weight gradient");
+  const long long per = (long long)kh * kw * cin * cout;
+  hipStream_t st = (hipStream_t)stream;
+  int slab0 = 0;
+  WgradArgs a;
+  for (int g = 0; g < n_groups; ++g) {
+    const fcvsr_view* x = xs + g, *gy = gys + g;
+    FCVSR_CHECK_ARG(x->dtype == FCVSR_F32 && gy->dtype == FCVSR_F32 && x->sc == 1 && gy->sc == 1 && x->ptr && gy->ptr && x->c == cin && gy->c == cout,
+                    "x and gy must be channel-contiguous f32 views of the same channel counts");
+    FCVSR_CHECK_ARG(x->sx % 4 == 0 && x->sy % 4 == 0 && x->sb % 4 == 0 && gy->sx % 4 == 0 && gy->sy % 4 == 0 && gy->sb % 4 == 0 &&
+                        ((uintptr_t)x->ptr % 16) == 0 && ((uintptr_t)gy->ptr % 16) == 0, "views must be 16-byte aligned");
+    a.x = to_view(*x); a.gy = to_view(*gy);
+    a.B = B[g]; a.H = H[g]; a.W = W[g]; a.kh = kh; a.kw = kw; a.stride = 1; a.pad = pad;
+    a.Ho = H[g]; a.Wo = W[g]; a.cin = cin; a.cout = cout;
+    a.npix = (long long)B[g] * H[g] * W[g];
+    a.n_slabs = wgrad_mfma_slabs(B[g], H[g], W[g], cin, cout);
+    FCVSR_CHECK_ARG(scratch_elems >= (long long)(slab0 + a.n_slabs) * per, "scratch too small (fcvsr_conv2d_wgrad_mfma_groups_scratch_elems)");
+    a.slab_pix = 0;
+    a.partial = scratch + (long long)slab0 * per; a.dw = dw;
+    const int tiles_x = cdiv(W[g], kGTX), tiles_y = cdiv(H[g], kGTY);
+    const int total = B[g] * tiles_x * tiles_y;
+    const int per_slab = (total + a.n_slabs - 1) / a.n_slabs;
+    const dim3 grid(a.n_slabs, (cin / 64) * (cout / 64));
+    if (kh == 3) {
+      const size_t ldsb = 64 * kGyPitch + 3 * 64 * ((kGTY + 2) * kGTX * 2 + 16);
+      static DevOnce attr3;
+      hipError_t e = once_per_device(attr3, [&] {
+        return hipFuncSetAttribute((const void*)wgrad_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+      });
+      if (e != hipSuccess) { set_error("fcvsr_conv2d_wgrad_mfma_groups: %s", hipGetErrorString(e)); return (int)e; }
+      hipLaunchKernelGGL(wgrad_mfma_kernel<3>, grid, dim3(256), ldsb, st, a, tiles_x, tiles_y, per_slab);
+    } else {
+      const size_t ldsb = 64 * kGyPitch + 64 * (kGTY * kGTX * 2 + 16);
+      hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), ldsb, st, a, tiles_x, tiles_y, per_slab);
+    }
+    FCVSR_LAUNCH_CHECK();
+    slab0 += a.n_slabs;
+  }
+  a.n_slabs = slab0;
+  a.partial = scratch;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, a);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}

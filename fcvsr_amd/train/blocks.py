@@ -172,3 +172,44 @@ def prelu(x: torch.Tensor, slope: torch.Tensor) -> torch.Tensor:
     if slope.numel() != 1 or x.numel() % 4:
         return torch.nn.functional.prelu(x, slope.reshape(-1))
     return _PReluFn.apply(x, slope)
+
+
+class _XscaleFn(torch.autograd.Function):
+    """One level of BlockRCB's cross-scale sum (reference CVSR_freq.py:766-777): out = x + r_scale * R + avgpool2(dn) + bilinear_up2(up)
+    (dn at twice, up at half the resolution; either may be absent) - fcvsr_xscale forward, the two resampling adjoints backward."""
+
+    @staticmethod
+    def forward(ctx, x, R, r_scale, dn, up):
+        xv, Rv = _nhwc(x.float()), _nhwc(R.float())
+        dv = None if dn is None else _nhwc(dn.float())
+        uv = None if up is None else _nhwc(up.float())
+        B, H, W, Cn = xv.shape
+        out = torch.empty_like(xv)
+        hip.check(hip.lib().fcvsr_xscale(xv.data_ptr(), Rv.data_ptr(), r_scale, hip.ptr(dv), hip.ptr(uv), out.data_ptr(), hip.F32, B, H, W, Cn,
+                                         hip.stream_ptr()), "fcvsr_xscale")
+        ctx.r_scale, ctx.has = r_scale, (dn is not None, up is not None)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        gv = _nhwc(g.float())
+        B, H, W, Cn = gv.shape
+        L = hip.lib()
+        gR = g if ctx.r_scale == 1.0 else g * ctx.r_scale
+        gdn = gup = None
+        if ctx.has[0]:
+            o = torch.empty((B, 2 * H, 2 * W, Cn), dtype=torch.float32, device=gv.device)
+            hip.check(L.fcvsr_pool2_adjoint(gv.data_ptr(), o.data_ptr(), B, H, W, Cn, hip.stream_ptr()), "fcvsr_pool2_adjoint")
+            gdn = o.permute(0, 3, 1, 2)
+        if ctx.has[1]:
+            o = torch.empty((B, H // 2, W // 2, Cn), dtype=torch.float32, device=gv.device)
+            hip.check(L.fcvsr_up2_adjoint(gv.data_ptr(), o.data_ptr(), B, H // 2, W // 2, Cn, hip.stream_ptr()), "fcvsr_up2_adjoint")
+            gup = o.permute(0, 3, 1, 2)
+        return g, gR, None, gdn, gup
+
+
+def xscale(x: torch.Tensor, R: torch.Tensor, r_scale: float, dn=None, up=None) -> torch.Tensor:
+    """x + r_scale * R + avgpool2(dn) + bilinear_up2(up) on (B,C,H,W) device tensors, H and W even, C % 4 == 0."""
+    if not x.is_cuda:
+        raise RuntimeError("fcvsr_amd.train.blocks needs device tensors (the HIP path has no CPU fallback)")
+    return _XscaleFn.apply(x, R, float(r_scale), dn, up)

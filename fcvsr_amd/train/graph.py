@@ -19,8 +19,8 @@ import torch
 import torch.nn.functional as F
 
 from ..engine import band_masks_half
-from .blocks import iac_both, prelu, rcb_tail
-from .ops import conv2d
+from .blocks import iac_both, prelu, rcb_tail, xscale
+from .ops import conv2d, conv2d_levels
 
 Tensor = torch.Tensor
 
@@ -123,25 +123,32 @@ def _sac(s: Tensor, k1: Tensor) -> Tensor:
 
 
 def _mgaa(c: _Ctx, key: str, x: Tensor, A: int) -> Tensor:
+    """MGAAbk.forward (:1442-1547).  The forward and the backward alignment direction share every weight, so they run STACKED on the
+    batch axis (2B) through convfuse / convcorr / the ConvBlk heads / the inverse transforms: half the launches, identical values."""
     B, C3, H, W = x.shape
     d = C3 // 3
     x1, x2, x3 = torch.split(x, d, dim=1)                            # (one cat in the backward instead of three zero-filled slices)
-    x1f, x2f, x3f = _spec(x1), _spec(x2), _spec(x3)
-    off_f = (x1f - x2f) + c.chain(key + ".convfuse", torch.cat([x1f, x2f], 1), 3)
-    off_b = (x3f - x2f) + c.chain(key + ".convfuse", torch.cat([x3f, x2f], 1), 3)
+    X = torch.fft.rfft2(x.contiguous(), norm="backward")             # one transform for the three groups
+    Xi, Xr = X.imag, X.real
+    spec = [torch.cat([Xi[:, g * d:(g + 1) * d], Xr[:, g * d:(g + 1) * d]], dim=1) for g in range(3)]   # imag first (:1456-1465)
+    x1f, x2f, x3f = spec
+    side = torch.cat([x1f, x3f], 0)                                  # (2B, 2d, H, Wf): forward direction, then backward
+    mid = torch.cat([x2f, x2f], 0)
+    off = (side - mid) + c.chain(key + ".convfuse", torch.cat([side, mid], 1), 3)
     sim = c.chain(key + ".convcrt", x2f, 2)
     corr = _corr_lookup(x1f, x2f)                                   # forward pair only, reused for both directions (:1487-1488)
-    flow0 = torch.zeros(B, 2, H, x1f.shape[-1], dtype=x.dtype, device=x.device)
-    off_f = c.chain(key + ".convcorr", torch.cat([off_f, corr, flow0], 1), 3)
-    off_b = c.chain(key + ".convcorr", torch.cat([off_b, corr, flow0], 1), 3)
+    flow0 = torch.zeros(2 * B, 2, H, x1f.shape[-1], dtype=x.dtype, device=x.device)
+    off = c.chain(key + ".convcorr", torch.cat([off, torch.cat([corr, corr], 0), flow0], 1), 3)
+    sim2 = torch.cat([sim, sim], 0)
     offs: List[List[Tensor]] = [[], []]
     for i in range(A):
         blk = f"{key}.MConvB.{i}"
-        for src, dst in ((off_f, offs[0]), (off_b, offs[1])):
-            t = _prelu(c.conv(blk + ".conv1", src), c.p[blk + ".relu.weight"])
-            u = c.conv(blk + ".conv2", t)
-            o = (c.ca(blk + ".CA", u) + u) * sim
-            dst.append(torch.fft.irfft2(torch.complex(o[:, :2].contiguous(), o[:, 2:].contiguous()), s=(H, W), norm="backward"))
+        t = _prelu(c.conv(blk + ".conv1", off), c.p[blk + ".relu.weight"])
+        u = c.conv(blk + ".conv2", t)
+        o = (c.ca(blk + ".CA", u) + u) * sim2
+        fld = torch.fft.irfft2(torch.complex(o[:, :2].contiguous(), o[:, 2:].contiguous()), s=(H, W), norm="backward")
+        offs[0].append(fld[:B])
+        offs[1].append(fld[B:])
     K = c.conv(key + ".F.1", c.conv(key + ".F.0", c.conv(key + ".conv_KP", x2)))
     if c.fused_blocks and d in (32, 64):
         a_f, a_b = iac_both(x1, x3, K, offs[0], offs[1], 0.1)
@@ -201,22 +208,27 @@ def _context_block(c: _Ctx, key: str, r: Tensor) -> Tensor:
 
 
 def _block_rcb(c: _Ctx, key: str, xs: List[Tensor]) -> List[Tensor]:
-    def body(z):
-        z = c.conv(key + ".body.2", c.conv(key + ".body.0", z, act="lrelu", slope=0.1))
-        r = c.conv(key + ".RCB.body.2", c.conv(key + ".RCB.body.0", z, act="lrelu", slope=0.2))
+    def lv(name, ts, act=None, slope=0.0):
+        """one nn.Conv2d on every pyramid level (shared weights): grouped launches where the layer allows"""
+        return conv2d_levels(ts, c.p[name + ".weight"], c.p.get(name + ".bias"), c.precision, act, slope)
+
+    zs = lv(key + ".body.2", lv(key + ".body.0", xs, "lrelu", 0.1))
+    rs = lv(key + ".RCB.body.2", lv(key + ".RCB.body.0", zs, "lrelu", 0.2))
+    R = []
+    for r, z in zip(rs, zs):
         if r.shape[1] == 64 and c.fused_blocks:
             g = key + ".RCB.gcnet"
-            return rcb_tail(r, z, c.p[g + ".conv_mask.weight"], c.p[g + ".channel_add_conv.0.weight"], c.p[g + ".channel_add_conv.2.weight"], 0.2)
-        return _lrelu(_context_block(c, key + ".RCB.gcnet", r), 0.2) + z
-
-    def dn(z):
-        return F.interpolate(c.conv(key + ".down.0", z), scale_factor=0.5, mode="bilinear", align_corners=False)
-
-    def up(z):
-        return F.interpolate(c.conv(key + ".up.0", z), scale_factor=2.0, mode="bilinear", align_corners=False)
-
-    R = [body(z) for z in xs]
-    return [xs[0] + R[0] + R[0] + up(R[1]), xs[1] + R[1] + dn(R[0]) + up(R[2]), xs[2] + R[2] + dn(R[1]) + R[2]]
+            R.append(rcb_tail(r, z, c.p[g + ".conv_mask.weight"], c.p[g + ".channel_add_conv.0.weight"], c.p[g + ".channel_add_conv.2.weight"], 0.2))
+        else:
+            R.append(_lrelu(_context_block(c, key + ".RCB.gcnet", r), 0.2) + z)
+    d0, d1 = lv(key + ".down.0", [R[0], R[1]])
+    u1, u2 = lv(key + ".up.0", [R[1], R[2]])
+    if c.fused_blocks and all(t.shape[2] % 2 == 0 and t.shape[3] % 2 == 0 for t in xs[:2]) and xs[0].shape[1] % 4 == 0:
+        # (for even sizes the x0.5 bilinear down-sampling is the 2x2 mean; the doubled R0 / R2 of :771-776 are r_scale = 2)
+        return [xscale(xs[0], R[0], 2.0, None, u1), xscale(xs[1], R[1], 1.0, d0, u2), xscale(xs[2], R[2], 2.0, d1, None)]
+    dn = [F.interpolate(t, scale_factor=0.5, mode="bilinear", align_corners=False) for t in (d0, d1)]
+    up = [F.interpolate(t, scale_factor=2.0, mode="bilinear", align_corners=False) for t in (u1, u2)]
+    return [xs[0] + R[0] + R[0] + up[0], xs[1] + R[1] + dn[0] + up[1], xs[2] + R[2] + dn[1] + R[2]]
 
 
 def _scnet(c: _Ctx, key: str, xs: List[Tensor], G: int) -> List[Tensor]:
@@ -225,7 +237,8 @@ def _scnet(c: _Ctx, key: str, xs: List[Tensor], G: int) -> List[Tensor]:
         t = cur
         for k in range(3):
             t = _block_rcb(c, f"{key}.body.{g}.body.{k}", t)
-        cur = [a + c.conv(f"{key}.body.{g}.conv", r) for a, r in zip(cur, t)]
+        cv = conv2d_levels(t, c.p[f"{key}.body.{g}.conv.weight"], c.p.get(f"{key}.body.{g}.conv.bias"), c.precision)
+        cur = [a + r for a, r in zip(cur, cv)]
     return [x + r for x, r in zip(xs, cur)]
 
 
@@ -243,8 +256,8 @@ def forward_train(p: Dict[str, Tensor], x: Tensor, *, precision: str = "f32", fu
     c = _Ctx(p, precision, fused_blocks)
     feat = conv2d(x.reshape(B, T * C, H, W).float(), p["feat_extract.0.weight"], p["feat_extract.0.bias"], 1, "f32")
     f1, f2, f3 = feat[:, :3 * n], feat[:, 3 * n:4 * n], feat[:, 4 * n:]
-    a1 = _mgaa(c, "MGAA", f1, A)
-    a3 = _mgaa(c, "MGAA", f3, A)
+    a13 = _mgaa(c, "MGAA", torch.cat([f1, f3], 0), A)               # the two outer calls share the weights: one call on 2B samples
+    a1, a3 = a13[:B], a13[B:]
     a2 = _mgaa(c, "MGAA", torch.cat([a1, f2, a3], 1), A)
     d0 = _mffr(c, "MFFRblock", a2, Q)
     d1 = c.conv("rconcat1", d0, stride=2)

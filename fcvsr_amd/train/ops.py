@@ -165,3 +165,82 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     if not x.is_cuda:
         raise RuntimeError("fcvsr_amd.train.conv2d needs device tensors (the HIP path has no CPU fallback)")
     return _Conv2dFn.apply(x, w, bias, stride, precision, _ACT[act], float(slope))
+
+
+class _ConvLevelsFn(torch.autograd.Function):
+    """One nn.Conv2d applied to several tensors of different sizes (the pyramid levels of a BlockRCB layer, reference
+    CVSR_freq.py:766-777) as ONE forward launch, ONE input-gradient launch, one matrix-core weight-gradient launch per level with a
+    single ordered reduction, and one bias-gradient reduction - instead of three independent layers whose gradients autograd adds.
+    16-bit modes, stride 1, cin and cout multiples of 64 (the wrapper checks)."""
+
+    @staticmethod
+    def forward(ctx, w, bias, precision, act, slope, *xs):
+        mdt, tdt = _MMA[precision]
+        cout, cin, k, _ = w.shape
+        xvs = [_nhwc(x.float()) for x in xs]
+        outs = [torch.empty((xv.shape[0], xv.shape[1], xv.shape[2], cout), dtype=torch.float32, device=xv.device) for xv in xvs]
+        b = None if bias is None else bias.detach().float().contiguous()
+        hip.conv2d_mfma([dict(srcs=[xv], dst=o) for xv, o in zip(xvs, outs)], packed_weight_mfma(w, tdt, False), k, cout, mdt, bias=b,
+                        act=act, slope=slope)
+        ctx.save_for_backward(w, *xvs, *(outs if act != hip.ACT_NONE else []))
+        ctx.n, ctx.precision, ctx.has_bias, ctx.act, ctx.slope = len(xs), precision, bias is not None, act, slope
+        return tuple(o.permute(0, 3, 1, 2) for o in outs)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        n = ctx.n
+        w = ctx.saved_tensors[0]
+        xvs = ctx.saved_tensors[1:1 + n]
+        ys = ctx.saved_tensors[1 + n:]
+        mdt, tdt = _MMA[ctx.precision]
+        cout, cin, k, _ = w.shape
+        L = hip.lib()
+        st = hip.stream_ptr()
+        gvs = []
+        for i, gy in enumerate(gys):
+            gv = _nhwc(gy.float())
+            if ctx.act != hip.ACT_NONE:
+                gp = torch.empty_like(gv)
+                hip.check(L.fcvsr_act_bwd(gv.data_ptr(), ys[i].data_ptr(), gp.data_ptr(), ctx.slope if ctx.act == hip.ACT_LEAKY else 0.0,
+                                          gv.numel(), st), "fcvsr_act_bwd")
+                gv = gp
+            gvs.append(gv)
+        gxs = [None] * n
+        if any(ctx.needs_input_grad[5:]):
+            gx = [torch.empty_like(xv) for xv in xvs]
+            hip.conv2d_mfma([dict(srcs=[gv], dst=o) for gv, o in zip(gvs, gx)], packed_weight_mfma(w, tdt, True), k, cin, mdt)
+            gxs = [o.permute(0, 3, 1, 2) for o in gx]
+        gw = gb = None
+        if ctx.needs_input_grad[0]:
+            Bs = (C.c_int * n)(*[xv.shape[0] for xv in xvs])
+            Hs = (C.c_int * n)(*[xv.shape[1] for xv in xvs])
+            Ws = (C.c_int * n)(*[xv.shape[2] for xv in xvs])
+            ne = L.fcvsr_conv2d_wgrad_mfma_groups_scratch_elems(Bs, Hs, Ws, n, cin, cout, k, k)
+            scratch = torch.empty(ne, dtype=torch.float32, device=w.device)
+            gw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=w.device)
+            xd = (hip.View * n)(*[hip.view(xv) for xv in xvs])
+            gd = (hip.View * n)(*[hip.view(gv) for gv in gvs])
+            hip.check(L.fcvsr_conv2d_wgrad_mfma_groups(xd, gd, Bs, Hs, Ws, n, k, k, k // 2, gw.data_ptr(), scratch.data_ptr(), ne, st),
+                      "fcvsr_conv2d_wgrad_mfma_groups")
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            ptrs = (C.c_void_p * n)(*[gv.data_ptr() for gv in gvs])
+            npx = (C.c_longlong * n)(*[gv.numel() // cout for gv in gvs])
+            ne = L.fcvsr_colsum_groups_scratch_elems(npx, n, cout)
+            scratch = torch.empty(ne, dtype=torch.float32, device=w.device)
+            gb = torch.empty(cout, dtype=torch.float32, device=w.device)
+            hip.check(L.fcvsr_colsum_groups(ptrs, npx, n, cout, gb.data_ptr(), scratch.data_ptr(), ne, st), "fcvsr_colsum_groups")
+        return (gw, gb, None, None, None, *gxs)
+
+
+def conv2d_levels(xs, w: torch.Tensor, bias: Optional[torch.Tensor] = None, precision: str = "f32", act: Optional[str] = None,
+                  slope: float = 0.0):
+    """[act(conv(x)) for x in xs] for ONE stride-1 layer applied to up to three tensors (pyramid levels): grouped launches in the 16-bit
+    modes when the layer takes the matrix-core path in every direction; otherwise a plain loop over `conv2d`."""
+    xs = list(xs)
+    cout, cin, k, _ = w.shape
+    ok = (precision in _MMA and 1 < len(xs) <= 3 and k in (1, 3) and cin % 64 == 0 and cout % 64 == 0 and all(x.is_cuda for x in xs))
+    if ok:
+        ok = hip.mfma_eligible(k, 1, [dict(srcs=[_nhwc(x.float())], dst=_nhwc(x.float())) for x in xs])
+    if not ok:
+        return [conv2d(x, w, bias, 1, precision, act, slope) for x in xs]
+    return list(_ConvLevelsFn.apply(w, bias, precision, _ACT[act], float(slope), *xs))

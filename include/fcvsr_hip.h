@@ -136,6 +136,9 @@ int fcvsr_rcbt_forward(const float* r, const float* z, const float* wmask, const
 int fcvsr_rcbt_backward(const float* r, const float* g, const float* wmask, const float* w1, const float* w2, const float* stats,
                         float slope, int B, int HW, int C, float* gr, float* dwmask, float* dw1, float* dw2, float* scratch,
                         long long scratch_elems, void* stream);
+long long fcvsr_colsum_groups_scratch_elems(const long long* npix, int n_groups, int C);
+int fcvsr_colsum_groups(const float* const* xs, const long long* npix, int n_groups, int C, float* out, float* scratch,
+                        long long scratch_elems, void* stream);   /* column sums of 1..3 matrices added together, one ordered second stage */
 /* PReLU with one shared slope (nn.PReLU(), CVSR_freq.py:2590 / ConvBlk :349), slope in device memory:
  *   fcvsr_prelu_fwd: y = x > 0 ? x : slope[0] * x;   fcvsr_prelu_bwd: gx and gslope[0] (two-stage sum; scratch >= 2048 floats). */
 int fcvsr_prelu_fwd(const float* x, const float* slope, float* y, long long n, void* stream);
@@ -154,6 +157,17 @@ int fcvsr_iac_bwd_sac(const float* gy, const float* yout, const float* v, const 
                       int W, int C, float* gfin, int fin_accumulate, float* gv, const fcvsr_view* gk, int k_accumulate, void* stream);
 int fcvsr_iac_bwd_warp(const float* gv, const fcvsr_view* k1, const float* prev, const fcvsr_view* off, int B, int H, int W, int C,
                        float* gprev_zeroed, float* goff, void* stream);
+/* fcvsr_conv2d_wgrad_mfma summed over 1..3 problems that share the weight (the pyramid levels of a BlockRCB layer): one launch per
+ * problem into consecutive slab ranges of one scratch buffer and ONE ordered reduction (no per-level gradient tensors). */
+long long fcvsr_conv2d_wgrad_mfma_groups_scratch_elems(const int* B, const int* H, const int* W, int n_groups, int cin, int cout, int kh,
+                                                       int kw);
+int fcvsr_conv2d_wgrad_mfma_groups(const fcvsr_view* xs, const fcvsr_view* gys, const int* B, const int* H, const int* W, int n_groups, int kh,
+                                   int kw, int pad, float* dw, float* scratch, long long scratch_elems, void* stream);
+/* Adjoints of the two resamplings inside fcvsr_xscale (BlockRCB cross-scale sum under training), f32 NHWC:
+ *   fcvsr_up2_adjoint:   g (B,2H,2W,C) -> (B,H,W,C), transposed x2 bilinear up-sampling (align_corners = False, clamped);
+ *   fcvsr_pool2_adjoint: g (B,H,W,C) -> (B,2H,2W,C), transposed 2x2 mean. */
+int fcvsr_up2_adjoint(const float* g, float* out, int B, int H, int W, int C, void* stream);
+int fcvsr_pool2_adjoint(const float* g, float* out, int B, int H, int W, int C, void* stream);
 /* Diagnostic (FCVSR_RES_STAMPS=1 in the environment): copies the in-kernel cycle stamps the last resident-weight convolution
  * launch recorded for one workgroup, [wave 8][phase 64][slot 8] uint64, to host memory.  Not part of the data path. */
 int fcvsr_debug_res_stamps(void* host_out, size_t bytes);

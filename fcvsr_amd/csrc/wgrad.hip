@@ -9,6 +9,7 @@
 //
 // Layout: x and gy are channel-contiguous (NHWC) f32 views; the result is written in the reference's parameter layout
 // (cout, cin, kh, kw) so it can be returned as the .grad of the nn.Conv2d weight as is.
+#include <stdlib.h>
 #include "common.h"
 
 namespace fcvsr {
@@ -292,7 +293,16 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(WgradArgs a, int til
 
 static int wgrad_mfma_slabs(int B, int Ho, int Wo, int cin, int cout) {
   const int tiles = B * ((Ho + 3) / 4) * ((Wo + 31) / 32);
-  int n = 256 / ((cin / 64) * (cout / 64));             // one workgroup per CU
+  int n = 256 / ((cin / 64) * (cout / 64));             // at most one workgroup per CU
+  // Every slab writes (and the reduction reads) a full kh*kw*cin*cout f32 partial - 147 KB for a 64 -> 64 3x3 layer - so on the small
+  // problems of a training step (4 clips of 128 x 128: 512 tiles) one slab per CU moves more partial bytes than the layer has
+  // activations.  Measured all the same (round 3, 4 x 7 x 128 x 128 step, FCVSR_WGRAD_MIN_TILES = 1 / 4 / 8 / 16 / 32 tiles per slab: 43.1 /
+  // 47.4 / 56.0 / 74.8 / 112.5 ms per step): a tile costs a workgroup ~12 us of staging (the f32 -> bf16 transposes through LDS), so
+  // the default stays one slab per CU; the knob remains for larger batches.
+  static int min_tiles = -1;
+  if (min_tiles < 0) { const char* e = getenv("FCVSR_WGRAD_MIN_TILES"); min_tiles = e ? atoi(e) : 1; if (min_tiles < 1) min_tiles = 1; }
+  const int cap = (tiles + min_tiles - 1) / min_tiles;
+  if (n > cap) n = cap;
   if (n > tiles) n = tiles;
   if (n < 1) n = 1;
   return n;

@@ -20,7 +20,7 @@ import torch.nn.functional as F
 
 from ..engine import band_masks_half
 from .blocks import iac_both, prelu, rcb_tail, xscale
-from .ops import conv2d, conv2d_levels
+from .ops import clear_packed_weights, conv2d, conv2d_levels
 
 Tensor = torch.Tensor
 
@@ -33,6 +33,27 @@ class _Ctx:
     def conv(self, key: str, x: Tensor, stride: int = 1, act=None, slope: float = 0.0) -> Tensor:
         """nn.Conv2d + optional LeakyReLU / ReLU evaluated in the HIP kernel's epilogue (one launch)."""
         return conv2d(x, self.p[key + ".weight"], self.p.get(key + ".bias"), stride, self.precision, act, slope)
+
+    def conv_padded(self, key: str, parts: List[Tensor], act=None, slope: float = 0.0) -> Tensor:
+        """conv(cat(parts)) for a layer whose input-channel count is not a multiple of 64 (upconv_fuse 84, upconv1_L2_2 80, convcorr.0
+        211): in the 16-bit modes the concatenation is completed with a zero block and the weight with zero input columns, which makes the
+        layer eligible for the matrix-core kernels in all three directions (the exact-f32 VALU weight gradient of such a layer cost
+        0.1-0.3 ms).  Same values: the extra products are zeros."""
+        w, b = self.p[key + ".weight"], self.p.get(key + ".bias")
+        cin = w.shape[1]
+        cpad = (-cin) % 64
+        if self.precision == "f32" or cpad == 0 or w.shape[2] not in (1, 3):
+            return conv2d(torch.cat(parts, 1), w, b, 1, self.precision, act, slope)
+        ref = parts[0]
+        z = torch.zeros(ref.shape[0], cpad, ref.shape[2], ref.shape[3], dtype=ref.dtype, device=ref.device)
+        return conv2d(torch.cat(list(parts) + [z], 1), F.pad(w, (0, 0, 0, 0, 0, cpad)), b, 1, self.precision, act, slope)
+
+    def conv_s2(self, key: str, x: Tensor) -> Tensor:
+        """3x3 stride-2 convolution (rconcat1/2, :2594-2595).  16-bit modes: the stride-1 layer on the matrix cores, sub-sampled - 4x
+        the (cheap) products, but forward, input gradient and weight gradient all leave the f32 VALU kernels."""
+        if self.precision == "f32":
+            return self.conv(key, x, stride=2)
+        return self.conv(key, x)[:, :, ::2, ::2]
 
     def chain(self, key: str, t: Tensor, n: int) -> Tensor:
         """n bias-free 1x1 convolutions with ReLU in between (convfuse / convcrt / convcorr, CVSR_freq.py:1371-1396)."""
@@ -138,7 +159,9 @@ def _mgaa(c: _Ctx, key: str, x: Tensor, A: int) -> Tensor:
     sim = c.chain(key + ".convcrt", x2f, 2)
     corr = _corr_lookup(x1f, x2f)                                   # forward pair only, reused for both directions (:1487-1488)
     flow0 = torch.zeros(2 * B, 2, H, x1f.shape[-1], dtype=x.dtype, device=x.device)
-    off = c.chain(key + ".convcorr", torch.cat([off, torch.cat([corr, corr], 0), flow0], 1), 3)
+    t = c.conv_padded(key + ".convcorr.0", [off, torch.cat([corr, corr], 0), flow0], act="relu")       # 211 -> 64 (:1379-1385)
+    t = conv2d(t, c.p[key + ".convcorr.2.weight"], None, 1, c.precision, "relu")
+    off = conv2d(t, c.p[key + ".convcorr.4.weight"], None, 1, c.precision)
     sim2 = torch.cat([sim, sim], 0)
     offs: List[List[Tensor]] = [[], []]
     for i in range(A):
@@ -253,23 +276,37 @@ def forward_train(p: Dict[str, Tensor], x: Tensor, *, precision: str = "f32", fu
     B, T, C, H, W = x.shape
     if H % 4 or W % 4:
         raise ValueError("H and W must be multiples of 4 (3-level pyramid, reference BlockRCB :766-777)")
+    # The packed 16-bit weight operands are cached per (storage pointer, version) for the duration of ONE forward + backward pass (a
+    # layer applied several times packs once).  Across passes the cache must not survive: the optimizer rewrites every weight, and a
+    # freed model's storage can be handed to another parameter of the same shape and version.  Clearing here also guarantees that a
+    # hipGraph capture records the packing kernels of its pass.
+    clear_packed_weights()
     c = _Ctx(p, precision, fused_blocks)
-    feat = conv2d(x.reshape(B, T * C, H, W).float(), p["feat_extract.0.weight"], p["feat_extract.0.bias"], 1, "f32")
+    x7 = x.reshape(B, T * C, H, W).float()
+    if precision == "f32" or (T * C) % 64 == 0:
+        feat = conv2d(x7, p["feat_extract.0.weight"], p["feat_extract.0.bias"], 1, "f32")
+    else:
+        # 16-bit modes: the frame stack completed with zero channels to 64 and the weight with zero input columns, products in f16
+        # (8-bit pixel values stay exact, as in the inference engine): forward and weight gradient on the matrix cores - the exact-f32
+        # VALU weight gradient of this 7 -> 448 layer alone cost 1.1 ms per step
+        cpad = (-(T * C)) % 64
+        xz = torch.cat([x7, torch.zeros(B, cpad, H, W, dtype=x7.dtype, device=x7.device)], 1).contiguous(memory_format=torch.channels_last)
+        feat = conv2d(xz, F.pad(p["feat_extract.0.weight"], (0, 0, 0, 0, 0, cpad)), p["feat_extract.0.bias"], 1, "f16")
     f1, f2, f3 = feat[:, :3 * n], feat[:, 3 * n:4 * n], feat[:, 4 * n:]
     a13 = _mgaa(c, "MGAA", torch.cat([f1, f3], 0), A)               # the two outer calls share the weights: one call on 2B samples
     a1, a3 = a13[:B], a13[B:]
     a2 = _mgaa(c, "MGAA", torch.cat([a1, f2, a3], 1), A)
     d0 = _mffr(c, "MFFRblock", a2, Q)
-    d1 = c.conv("rconcat1", d0, stride=2)
-    d2 = c.conv("rconcat2", d1, stride=2)
+    d1 = c.conv_s2("rconcat1", d0)
+    d2 = c.conv_s2("rconcat2", d1)
     o0, o1, o2 = _scnet(c, "recorb1", [d0, d1, d2], G)
     a = p["lrelu.weight"]
     l3 = _prelu(c.conv("upconv1_L3", o2), a)
     l3_1 = _ps2(l3)
     l3_2 = _ps2(l3_1)
     l2 = _prelu(c.conv("upconv1_L2", o1), a)
-    l2 = _ps2(l2 + c.conv("upconv1_L2_2", torch.cat([l2, l3_1], 1)))
-    fz = c.conv("recorb0", c.conv("upconv_fuse", torch.cat([o0, l2, l3_2], 1)))
+    l2 = _ps2(l2 + c.conv_padded("upconv1_L2_2", [l2, l3_1]))
+    fz = c.conv("recorb0", c.conv_padded("upconv_fuse", [o0, l2, l3_2]))
     u = _ps2(_prelu(c.conv("upconv1", fz), a))                      # PReLU (one shared slope) commutes with the shuffle: same values,
     u = _ps2(_prelu(c.conv("upconv2", u), a))                       # and the activation then runs on the dense conv output
     out = conv2d(u, p["conv_last0.weight"], p["conv_last0.bias"], 1, precision)   # (16-bit modes: a 4-channel MFMA layer, rows 1..3 zero)

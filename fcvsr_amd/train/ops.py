@@ -27,10 +27,15 @@ from .. import hip
 _MMA = {"bf16": (hip.BF16, torch.bfloat16), "f16": (hip.F16, torch.float16)}
 _ACT = {None: hip.ACT_NONE, "none": hip.ACT_NONE, "relu": hip.ACT_RELU, "lrelu": hip.ACT_LEAKY}
 
-# packed 16-bit weights per (storage pointer, parameter version, dtype, transposed): valid until the optimizer writes the
-# parameter (which bumps _version); bounded so that a long run cannot grow it
+# packed 16-bit weights per (storage pointer, parameter version, dtype, transposed), valid for ONE forward + backward pass
+# (graph.forward_train clears it): within a pass a layer that is applied several times packs once
 _PACKED: Dict[Tuple, torch.Tensor] = {}
 _PACKED_MAX = 4096
+
+
+def clear_packed_weights() -> None:
+    """Forget every cached operand packing (called at the start of each differentiable forward: see graph.forward_train)."""
+    _PACKED.clear()
 
 
 def _nhwc(t: torch.Tensor) -> torch.Tensor:

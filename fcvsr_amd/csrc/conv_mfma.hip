@@ -1152,8 +1152,7 @@ static hipError_t dispatch_lean(const MfmaArgs& a, int nt, int total_tiles, hipS
                       : launch_lean<BF16, NTV, true, false>(a, total_tiles, st))                                \
            : (a.dst16 ? launch_lean<BF16, NTV, false, true>(a, total_tiles, st)                                 \
                       : launch_lean<BF16, NTV, false, false>(a, total_tiles, st)))
-  if (nt == 128) return FCVSR_LEAN(128);
-  if (nt == 64) return FCVSR_LEAN(64);
+  if (nt == 64) return FCVSR_LEAN(64);     // (the 128-cout tile measured 0.65x and spilled: no longer built)
   return FCVSR_LEAN(32);
 #undef FCVSR_LEAN
 }
@@ -1177,18 +1176,16 @@ static hipError_t launch_mfma(const MfmaArgs& a, int total_tiles, hipStream_t st
 template <bool BF16, int MW, bool WD>
 static hipError_t dispatch2(const MfmaArgs& a, int nt, int ks, int total_tiles, hipStream_t st) {
   if (ks == 3) {
-    if (nt == 128) return launch_mfma<BF16, 128, 3, MW, WD>(a, total_tiles, st);
     if (nt == 64) return launch_mfma<BF16, 64, 3, MW, WD>(a, total_tiles, st);
     return launch_mfma<BF16, 32, 3, MW, WD>(a, total_tiles, st);
   }
-  if (nt == 128) return launch_mfma<BF16, 128, 1, MW, WD>(a, total_tiles, st);
   if (nt == 64) return launch_mfma<BF16, 64, 1, MW, WD>(a, total_tiles, st);
   return launch_mfma<BF16, 32, 1, MW, WD>(a, total_tiles, st);
 }
 
 template <bool BF16>
 static hipError_t dispatch(const MfmaArgs& a, int nt, int ks, int mw, int wd, int total_tiles, hipStream_t st) {
-  if (mw == 2) return dispatch2<BF16, 2, false>(a, nt, ks, total_tiles, st);
+  (void)mw;      // (8-row tiles - MW = 2 - measured 0.85-1.0x and their 128-cout instances spilled 176 scratch operations: not built)
   return wd ? dispatch2<BF16, 1, true>(a, nt, ks, total_tiles, st) : dispatch2<BF16, 1, false>(a, nt, ks, total_tiles, st);
 }
 
@@ -1262,10 +1259,6 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   // N tile: measured faster with <= 64 couts per workgroup (register pressure of 128-cout accumulators costs more than
   // re-staging the input tile for the second N-block); FCVSR_MFMA_NTMAX=128 restores the wide tile for experiments.
   int nt = d0.cout > 32 ? 64 : 32;
-  {
-    const char* e = getenv("FCVSR_MFMA_NTMAX");
-    if (e && atoi(e) == 128 && d0.cout > 64) nt = 128;
-  }
   a.n_nblk = (d0.cout + nt - 1) / nt;
   a.w = (const uint16_t*)d0.weight;
   a.bias = d0.bias;
@@ -1286,11 +1279,7 @@ extern "C" int fcvsr_conv2d_mfma(const fcvsr_conv_desc* descs, int n_groups, int
   }
   // tile rows per workgroup: 8 (2 per wave) or 4 (1 per wave: half the LDS -> more co-resident workgroups in
   // different phases).  FCVSR_MFMA_MW overrides for experiments.
-  int mw = 1;   // measured: 4-row tiles (more co-resident workgroups in different phases) win for 3x3 and 1x1 alike
-  {
-    const char* e = getenv("FCVSR_MFMA_MW");
-    if (e) mw = atoi(e) == 1 ? 1 : 2;
-  }
+  const int mw = 1;   // measured: 4-row tiles (more co-resident workgroups in different phases) win for 3x3 and 1x1 alike
   int wd = 0;     // weights straight from L2 into the B-operand registers (no LDS staging / tap barriers)
   {
     const char* e = getenv("FCVSR_MFMA_WD");

@@ -917,6 +917,28 @@ static int ilog2(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
       case 240: CALL(15, 16); break;  case 256: CALL(16, 16); break;  case 320: CALL(16, 20); break;         \
     }                                                                                                        \
   } while (0)
+// Column passes: the register butterflies of 15 x 16 / 16 x 20 points (and, with the band masks, 12 x 16 / 16 x 16 too) do not fit the
+// 128-register budget of the three-workgroups-per-CU column kernels - hipcc spilled them to scratch - so those lengths are not
+// built as two-stage COLUMN kernels: column transforms of 240 / 320 rows (192 / 256 with masks) take the multi-stage path.
+#define FCVSR_FFT2_DISPATCH_COLS(ts, CALL)                                                                   \
+  do {                                                                                                       \
+    switch ((ts).N) {                                                                                        \
+      case 64: CALL(8, 8); break;     case 72: CALL(8, 9); break;     case 80: CALL(8, 10); break;           \
+      case 96: CALL(8, 12); break;    case 128: CALL(8, 16); break;   case 144: CALL(12, 12); break;         \
+      case 160: CALL(10, 16); break;  case 180: CALL(12, 15); break;  case 192: CALL(12, 16); break;         \
+      case 256: CALL(16, 16); break;                                                                         \
+    }                                                                                                        \
+  } while (0)
+#define FCVSR_FFT2_DISPATCH_BANDS(ts, CALL)                                                                  \
+  do {                                                                                                       \
+    switch ((ts).N) {                                                                                        \
+      case 64: CALL(8, 8); break;     case 72: CALL(8, 9); break;     case 80: CALL(8, 10); break;           \
+      case 96: CALL(8, 12); break;    case 128: CALL(8, 16); break;   case 144: CALL(12, 12); break;         \
+      case 160: CALL(10, 16); break;  case 180: CALL(12, 15); break;                                         \
+    }                                                                                                        \
+  } while (0)
+static const TwoStage* two_stage_cols(int N) { return (N == 240 || N == 320) ? nullptr : two_stage(N); }
+static const TwoStage* two_stage_bands(int N) { return (N == 192 || N == 240 || N == 256 || N == 320) ? nullptr : two_stage(N); }
 
 static int launch_cols2(const TwoStage& ts, const float* in, float* out, long long ps, int im_off, int re_off, int n, int Wf,
                         int B, bool inverse, const float* mask, hipStream_t st) {
@@ -933,7 +955,7 @@ static int launch_cols2(const TwoStage& ts, const float* in, float* out, long lo
                                        re_off, n, Wf, logL, mask, tw, B);                                                    \
   else hipLaunchKernelGGL((fft_cols2_kernel<A_, B_, false, false>), grid, block, lds, st, in, out, ps, im_off, re_off, n,   \
                           Wf, logL, mask, tw, B)
-  FCVSR_FFT2_DISPATCH(ts, FCVSR_COLS2);
+  FCVSR_FFT2_DISPATCH_COLS(ts, FCVSR_COLS2);
 #undef FCVSR_COLS2
   return 0;
 }
@@ -948,7 +970,7 @@ static int launch_cols2_bands(const TwoStage& ts, const float* in, float* out, l
   const size_t lds = 8ull * ts.N * L + 8ull * ts.N;
 #define FCVSR_COLS2B(A_, B_) \
   hipLaunchKernelGGL((fft_cols2_bands_kernel<A_, B_>), grid, block, lds, st, in, out, out_band_stride, ps, im_off, re_off, n, Wf, logL, masks, nm, tw, B)
-  FCVSR_FFT2_DISPATCH(ts, FCVSR_COLS2B);
+  FCVSR_FFT2_DISPATCH_BANDS(ts, FCVSR_COLS2B);
 #undef FCVSR_COLS2B
   return 0;
 }
@@ -1041,7 +1063,7 @@ extern "C" int fcvsr_rfft2(const fcvsr_view* src, int B, int H, int W, int n, fl
   const bool spec_ok = pix_stride % 4 == 0 && im_off % 4 == 0 && re_off % 4 == 0 && ((uintptr_t)spec % 16) == 0;
   const bool spec_pair = pix_stride % 2 == 0 && im_off % 2 == 0 && re_off % 2 == 0 && ((uintptr_t)spec % 8) == 0;
   const TwoStage* tsw = two_stage(W);
-  const TwoStage* tsh = two_stage(H);
+  const TwoStage* tsh = two_stage_cols(H);
   if (tsw && n % 2 == 0 && pair_ok(src) && spec_pair) {
     const int rc = launch_rfft_rows2(*tsw, src, n, B, H, spec, (long long)pix_stride, im_off, re_off, st);
     if (rc) return rc;
@@ -1090,7 +1112,7 @@ extern "C" int fcvsr_irfft2(const float* spec, int64_t pix_stride, int im_off, i
   const bool spec_ok = pix_stride % 4 == 0 && im_off % 4 == 0 && re_off % 4 == 0 && ((uintptr_t)spec % 16) == 0;
   const bool mid_pair = pix_stride % 2 == 0 && im_off % 2 == 0 && re_off % 2 == 0 && ((uintptr_t)mid % 8) == 0;
   const TwoStage* tsw = two_stage(W);
-  const TwoStage* tsh = two_stage(H);
+  const TwoStage* tsh = two_stage_cols(H);
   if (tsh) {
     const int rc = launch_cols2(*tsh, spec, mid, (long long)pix_stride, im_off, re_off, n, Wf, B, true, mask, st);
     if (rc) return rc;
@@ -1133,7 +1155,7 @@ extern "C" int fcvsr_irfft2_bands(const float* spec, int64_t pix_stride, int im_
   const int Wf = W / 2 + 1;
   const long long band = (long long)B * H * Wf * pix_stride;           // floats per band of `work`
   hipStream_t st = (hipStream_t)stream;
-  const TwoStage* tsh = two_stage(H);
+  const TwoStage* tsh = two_stage_bands(H);
   static const bool off = getenv("FCVSR_FFT_BANDS") && atoi(getenv("FCVSR_FFT_BANDS")) == 0;
   if (!tsh || off) {                                                    // no fused column pass for this height: band by band
     for (int m = 0; m < n_bands; ++m) {

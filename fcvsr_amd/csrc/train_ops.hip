@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ x
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ part, int nblk, int C, float* __restrict__ out) {
+static thread_local int g_colsum_accumulate = 0;                // fcvsr_colsum_set_accumulate: out += instead of out = (see wgrad.hip)
+__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ part, int nblk, int C, float* __restrict__ out, int accumulate) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;       // 4 threads per column, fixed combination order
   __shared__ float sm[4][64];
   float s = 0.f;
@@ -89,7 +90,10 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ p
   }
   sm[q][threadIdx.x & 63] = s;
   __syncthreads();
-  if (q == 0 && c < C) out[c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+  if (q == 0 && c < C) {
+    const float t = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 // PReLU with ONE shared slope (nn.PReLU(), reference CVSR_freq.py:2590 and ConvBlk :349): y = x > 0 ? x : a x, slope read from device
@@ -217,7 +221,7 @@ extern "C" int fcvsr_colsum(const float* x, long long npix, int C, float* out, f
   const long long nblk = (npix + rpb - 1) / rpb;
   FCVSR_CHECK_ARG(scratch_elems >= nblk * C, "scratch too small");
   hipLaunchKernelGGL(colsum_stage1, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, npix, C, rpb, scratch);
-  hipLaunchKernelGGL(colsum_stage2, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, scratch, (int)nblk, C, out);
+  hipLaunchKernelGGL(colsum_stage2, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, scratch, (int)nblk, C, out, g_colsum_accumulate);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }
@@ -264,7 +268,7 @@ extern "C" int fcvsr_wgrad_cout1(const float* x, const float* gy, int B, int H, 
   FCVSR_CHECK_ARG(((uintptr_t)x % 16) == 0, "x 16-byte aligned");
   hipLaunchKernelGGL(wgrad_cout1_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, gy, B, H, W, C, rpb, scratch);
   // column sums of the (nb, C*9) partial matrix in block order = dw in nn.Conv2d's (1, C, 3, 3) layout
-  hipLaunchKernelGGL(colsum_stage2, dim3((9 * C + 63) / 64), dim3(256), 0, (hipStream_t)stream, scratch, nb, 9 * C, dw);
+  hipLaunchKernelGGL(colsum_stage2, dim3((9 * C + 63) / 64), dim3(256), 0, (hipStream_t)stream, scratch, nb, 9 * C, dw, g_colsum_accumulate);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }
@@ -289,7 +293,9 @@ extern "C" int fcvsr_colsum_groups(const float* const* xs, const long long* npix
     hipLaunchKernelGGL(colsum_stage1, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, xs[g], npix[g], C, rpb, scratch + blk0 * C);
     blk0 += nblk;
   }
-  hipLaunchKernelGGL(colsum_stage2, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, scratch, (int)blk0, C, out);
+  hipLaunchKernelGGL(colsum_stage2, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, scratch, (int)blk0, C, out, g_colsum_accumulate);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }
+
+extern "C" void fcvsr_colsum_set_accumulate(int on) { g_colsum_accumulate = on ? 1 : 0; }

@@ -22,7 +22,13 @@ struct WgradArgs {
   long long slab_pix;      // pixels per slab
   float* partial;          // [n_slabs][kh*kw][cin][cout]
   float* dw;               // [cout][cin][kh][kw]
+  int accumulate;          // 1: dw += the sum (the gradient buffer was zeroed at the start of the pass), 0: dw = the sum
 };
+
+// Per-thread switch of the three weight-gradient entry points between "dw = sum" and "dw += sum": the training step keeps every
+// parameter gradient in one flat, pre-zeroed buffer and lets the reduction add straight into it, which removes autograd's
+// AccumulateGrad addition per parameter and pass (fcvsr_wgrad_set_accumulate; fcvsr_amd/train/ops.py).
+static thread_local int g_wgrad_accumulate = 0;
 
 constexpr int kWgCo = 16, kWgCi = 64, kWgPx = 32;
 
@@ -118,7 +124,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
     s += p0; s += p1; s += p2; s += p3;
   }
   for (; sl < a.n_slabs; ++sl) s += a.partial[(long long)sl * n + j];
-  a.dw[((long long)co * a.cin + ci) * taps + tap] = s;
+  float* o = a.dw + ((long long)co * a.cin + ci) * taps + tap;
+  *o = a.accumulate ? *o + s : s;
 }
 
 }  // namespace fcvsr
@@ -155,7 +162,7 @@ extern "C" int fcvsr_conv2d_wgrad(const fcvsr_view* x, const fcvsr_view* gy, int
   a.slab_pix = (a.npix + a.n_slabs - 1) / a.n_slabs;
   a.slab_pix = (a.slab_pix + kWgPx - 1) / kWgPx * kWgPx;
   a.partial = scratch;
-  a.dw = dw;
+  a.dw = dw; a.accumulate = g_wgrad_accumulate;
   hipStream_t st = (hipStream_t)stream;
   const int nco = (a.cout + kWgCo - 1) / kWgCo, nci = (a.cin + kWgCi - 1) / kWgCi;
   FCVSR_CHECK_ARG(kh * kw <= 65535 && (long long)nco * nci <= 65535, "grid too large");
@@ -333,7 +340,7 @@ extern "C" int fcvsr_conv2d_wgrad_mfma(const fcvsr_view* x, const fcvsr_view* gy
   a.n_slabs = wgrad_mfma_slabs(B, H, W, a.cin, a.cout);
   FCVSR_CHECK_ARG(scratch_elems >= (long long)a.n_slabs * kh * kw * a.cin * a.cout, "scratch too small (fcvsr_conv2d_wgrad_mfma_scratch_elems)");
   a.slab_pix = 0;
-  a.partial = scratch; a.dw = dw;
+  a.partial = scratch; a.dw = dw; a.accumulate = g_wgrad_accumulate;
   const int tiles_x = cdiv(W, kGTX), tiles_y = cdiv(H, kGTY);
   const int total = B * tiles_x * tiles_y;
   const int per_slab = (total + a.n_slabs - 1) / a.n_slabs;
@@ -391,7 +398,7 @@ extern "C" int fcvsr_conv2d_wgrad_mfma_groups(const fcvsr_view* xs, const fcvsr_
     a.n_slabs = wgrad_mfma_slabs(B[g], H[g], W[g], cin, cout);
     FCVSR_CHECK_ARG(scratch_elems >= (long long)(slab0 + a.n_slabs) * per, "scratch too small (fcvsr_conv2d_wgrad_mfma_groups_scratch_elems)");
     a.slab_pix = 0;
-    a.partial = scratch + (long long)slab0 * per; a.dw = dw;
+    a.partial = scratch + (long long)slab0 * per; a.dw = dw; a.accumulate = g_wgrad_accumulate;
     const int tiles_x = cdiv(W[g], kGTX), tiles_y = cdiv(H[g], kGTY);
     const int total = B[g] * tiles_x * tiles_y;
     const int per_slab = (total + a.n_slabs - 1) / a.n_slabs;
@@ -417,3 +424,6 @@ extern "C" int fcvsr_conv2d_wgrad_mfma_groups(const fcvsr_view* xs, const fcvsr_
   FCVSR_LAUNCH_CHECK();
   return 0;
 }
+
+extern "C" void fcvsr_wgrad_set_accumulate(int on) { g_wgrad_accumulate = on ? 1 : 0; }
+extern "C" int fcvsr_wgrad_get_accumulate(void) { return g_wgrad_accumulate; }

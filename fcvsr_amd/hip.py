@@ -134,12 +134,15 @@ SIGNATURES = {
     "fcvsr_colsum_groups": [_VP, _VP, _I, _I, _VP, _VP, C.c_longlong, _VP],
     "fcvsr_up2_adjoint": [_VP, _VP, _I, _I, _I, _I, _VP],
     "fcvsr_pool2_adjoint": [_VP, _VP, _I, _I, _I, _I, _VP],
+    "fcvsr_wgrad_set_accumulate": [_I],
+    "fcvsr_wgrad_get_accumulate": [],
+    "fcvsr_colsum_set_accumulate": [_I],
     "fcvsr_rcbt_nblk": [_I],
     "fcvsr_rcbt_stat_elems": [],
     "fcvsr_rcbt_forward": [_VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, C.c_longlong, _VP],
     "fcvsr_rcbt_backward": [_VP, _VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, C.c_longlong, _VP],
 }
-_RESTYPES = {"fcvsr_last_error": C.c_char_p, "fcvsr_last_conv_kernel": C.c_char_p, "fcvsr_conv2d_wgrad_scratch_elems": C.c_longlong,
+_RESTYPES = {"fcvsr_wgrad_set_accumulate": None, "fcvsr_colsum_set_accumulate": None, "fcvsr_last_error": C.c_char_p, "fcvsr_last_conv_kernel": C.c_char_p, "fcvsr_conv2d_wgrad_scratch_elems": C.c_longlong,
              "fcvsr_conv2d_wgrad_mfma_scratch_elems": C.c_longlong, "fcvsr_colsum_scratch_elems": C.c_longlong,
              "fcvsr_wgrad_cout1_scratch_elems": C.c_longlong, "fcvsr_conv2d_wgrad_mfma_groups_scratch_elems": C.c_longlong,
              "fcvsr_colsum_groups_scratch_elems": C.c_longlong}

@@ -33,6 +33,35 @@ _PACKED: Dict[Tuple, torch.Tensor] = {}
 _PACKED_MAX = 4096
 
 
+# While True (TrainStep sets it around loss.backward()), the weight / bias gradient of a layer whose parameter already owns a dense f32
+# `.grad` (a view of the step's flat, pre-zeroed gradient buffer) is ADDED into that tensor by the reduction kernel itself and the
+# autograd Function returns None for it: no AccumulateGrad addition per parameter and pass.  Off by default: plain
+# `loss.backward()` / `torch.autograd.grad` see ordinary gradients.
+ACCUMULATE_INTO_GRAD = False
+
+
+class accumulate_into_grad:
+    """Context manager: let the HIP reductions add parameter gradients straight into existing `.grad` tensors."""
+
+    def __enter__(self):
+        global ACCUMULATE_INTO_GRAD
+        self._old, ACCUMULATE_INTO_GRAD = ACCUMULATE_INTO_GRAD, True
+
+    def __exit__(self, *exc):
+        global ACCUMULATE_INTO_GRAD
+        ACCUMULATE_INTO_GRAD = self._old
+
+
+def _grad_sink(p: Optional[torch.Tensor]):
+    """The parameter's `.grad` if the reductions may add into it in place, else None."""
+    if not ACCUMULATE_INTO_GRAD or p is None:
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or g.device != p.device:
+        return None
+    return g
+
+
 def clear_packed_weights() -> None:
     """Forget every cached operand packing (called at the start of each differentiable forward: see graph.forward_train)."""
     _PACKED.clear()
@@ -97,14 +126,15 @@ def _run_conv(x_nhwc: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
     return out
 
 
-def _colsum(g_nhwc: torch.Tensor) -> torch.Tensor:
-    """Sum over (b, y, x) of a dense (B,H,W,C) f32 tensor: the bias gradient."""
+def _colsum(g_nhwc: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Sum over (b, y, x) of a dense (B,H,W,C) f32 tensor: the bias gradient (written, or - in accumulate mode - added, to `out`)."""
     Cn = g_nhwc.shape[3]
     npix = g_nhwc.numel() // Cn
     L = hip.lib()
     n = L.fcvsr_colsum_scratch_elems(npix, Cn)
     scratch = torch.empty(n, dtype=torch.float32, device=g_nhwc.device)
-    out = torch.empty(Cn, dtype=torch.float32, device=g_nhwc.device)
+    if out is None:
+        out = torch.empty(Cn, dtype=torch.float32, device=g_nhwc.device)
     hip.check(L.fcvsr_colsum(g_nhwc.data_ptr(), npix, Cn, out.data_ptr(), scratch.data_ptr(), n, hip.stream_ptr()), "fcvsr_colsum")
     return out
 
@@ -114,13 +144,13 @@ class _Conv2dFn(torch.autograd.Function):
     def forward(ctx, x, w, bias, stride, precision, act, slope):
         xv = _nhwc(x.float())
         out = _run_conv(xv, w, bias, stride, precision, act=act, slope=slope)
-        ctx.save_for_backward(xv, w, out if act != hip.ACT_NONE else None)
+        ctx.save_for_backward(xv, w, out if act != hip.ACT_NONE else None, bias)
         ctx.stride, ctx.precision, ctx.has_bias, ctx.act, ctx.slope = stride, precision, bias is not None, act, slope
         return out.permute(0, 3, 1, 2)                    # (B,Cout,Ho,Wo), channels_last in memory
 
     @staticmethod
     def backward(ctx, gy):
-        xv, w, y = ctx.saved_tensors
+        xv, w, y, bias = ctx.saved_tensors
         stride, precision = ctx.stride, ctx.precision
         cout, cin, k, _ = w.shape
         B, H, W, _ = xv.shape
@@ -139,26 +169,44 @@ class _Conv2dFn(torch.autograd.Function):
                 g_in = torch.zeros((B, H, W, cout), dtype=torch.float32, device=gyv.device)
                 g_in[:, ::stride, ::stride, :][:, :gyv.shape[1], :gyv.shape[2]] = gyv
             gx = _run_conv(g_in, w, None, 1, precision, transposed=True).permute(0, 3, 1, 2)
-        if ctx.needs_input_grad[1] and cout == 1 and k == 3 and stride == 1 and cin in (16, 32, 64):
-            # one output channel (conv_last0): x is read once, 9 x cin accumulators per thread
-            n = L.fcvsr_wgrad_cout1_scratch_elems(B, H, cin)
-            scratch = torch.empty(n, dtype=torch.float32, device=xv.device)
-            gw = torch.empty((1, cin, 3, 3), dtype=torch.float32, device=xv.device)
-            hip.check(L.fcvsr_wgrad_cout1(xv.data_ptr(), gyv.data_ptr(), B, H, W, cin, gw.data_ptr(), scratch.data_ptr(), n, hip.stream_ptr()),
-                      "fcvsr_wgrad_cout1")
-        elif ctx.needs_input_grad[1]:
-            Ho, Wo = gyv.shape[1], gyv.shape[2]
-            # 16-bit modes: products on the matrix cores for the 3x3 / 1x1 layers with multiples of 64 channels; exact f32 otherwise
-            mm = precision in _MMA and L.fcvsr_conv2d_wgrad_mfma_eligible(cin, cout, k, k, stride, k // 2)
-            n = (L.fcvsr_conv2d_wgrad_mfma_scratch_elems if mm else L.fcvsr_conv2d_wgrad_scratch_elems)(B, Ho, Wo, cin, cout, k, k)
-            scratch = torch.empty(n, dtype=torch.float32, device=xv.device)
-            gw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=xv.device)
-            xd, gd = hip.view(xv), hip.view(gyv)
-            fn = L.fcvsr_conv2d_wgrad_mfma if mm else L.fcvsr_conv2d_wgrad
-            hip.check(fn(C.addressof(xd), C.addressof(gd), B, H, W, k, k, stride, k // 2, gw.data_ptr(), scratch.data_ptr(), n,
-                         hip.stream_ptr()), "fcvsr_conv2d_wgrad")
+        sink = _grad_sink(w) if ctx.needs_input_grad[1] else None      # add into the flat gradient buffer in place?
+        if sink is not None:
+            L.fcvsr_wgrad_set_accumulate(1)
+            L.fcvsr_colsum_set_accumulate(1)
+        try:
+            if ctx.needs_input_grad[1] and cout == 1 and k == 3 and stride == 1 and cin in (16, 32, 64):
+                # one output channel (conv_last0): x is read once, 9 x cin accumulators per thread
+                n = L.fcvsr_wgrad_cout1_scratch_elems(B, H, cin)
+                scratch = torch.empty(n, dtype=torch.float32, device=xv.device)
+                gw = sink if sink is not None else torch.empty((1, cin, 3, 3), dtype=torch.float32, device=xv.device)
+                hip.check(L.fcvsr_wgrad_cout1(xv.data_ptr(), gyv.data_ptr(), B, H, W, cin, gw.data_ptr(), scratch.data_ptr(), n, hip.stream_ptr()),
+                          "fcvsr_wgrad_cout1")
+            elif ctx.needs_input_grad[1]:
+                Ho, Wo = gyv.shape[1], gyv.shape[2]
+                # 16-bit modes: products on the matrix cores for the 3x3 / 1x1 layers with multiples of 64 channels; exact f32 otherwise
+                mm = precision in _MMA and L.fcvsr_conv2d_wgrad_mfma_eligible(cin, cout, k, k, stride, k // 2)
+                n = (L.fcvsr_conv2d_wgrad_mfma_scratch_elems if mm else L.fcvsr_conv2d_wgrad_scratch_elems)(B, Ho, Wo, cin, cout, k, k)
+                scratch = torch.empty(n, dtype=torch.float32, device=xv.device)
+                gw = sink if sink is not None else torch.empty((cout, cin, k, k), dtype=torch.float32, device=xv.device)
+                xd, gd = hip.view(xv), hip.view(gyv)
+                fn = L.fcvsr_conv2d_wgrad_mfma if mm else L.fcvsr_conv2d_wgrad
+                hip.check(fn(C.addressof(xd), C.addressof(gd), B, H, W, k, k, stride, k // 2, gw.data_ptr(), scratch.data_ptr(), n,
+                             hip.stream_ptr()), "fcvsr_conv2d_wgrad")
+        finally:
+            if sink is not None:
+                L.fcvsr_wgrad_set_accumulate(0)
+                L.fcvsr_colsum_set_accumulate(0)
+                gw = None                                             # already in w.grad
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = _colsum(gyv)
+            bsink = _grad_sink(bias)
+            if bsink is not None:
+                L.fcvsr_colsum_set_accumulate(1)
+                try:
+                    _colsum(gyv, out=bsink)
+                finally:
+                    L.fcvsr_colsum_set_accumulate(0)
+            else:
+                gb = _colsum(gyv)
         return gx, gw, gb, None, None, None, None
 
 
@@ -187,16 +235,16 @@ class _ConvLevelsFn(torch.autograd.Function):
         b = None if bias is None else bias.detach().float().contiguous()
         hip.conv2d_mfma([dict(srcs=[xv], dst=o) for xv, o in zip(xvs, outs)], packed_weight_mfma(w, tdt, False), k, cout, mdt, bias=b,
                         act=act, slope=slope)
-        ctx.save_for_backward(w, *xvs, *(outs if act != hip.ACT_NONE else []))
+        ctx.save_for_backward(w, bias, *xvs, *(outs if act != hip.ACT_NONE else []))
         ctx.n, ctx.precision, ctx.has_bias, ctx.act, ctx.slope = len(xs), precision, bias is not None, act, slope
         return tuple(o.permute(0, 3, 1, 2) for o in outs)
 
     @staticmethod
     def backward(ctx, *gys):
         n = ctx.n
-        w = ctx.saved_tensors[0]
-        xvs = ctx.saved_tensors[1:1 + n]
-        ys = ctx.saved_tensors[1 + n:]
+        w, bias = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        xvs = ctx.saved_tensors[2:2 + n]
+        ys = ctx.saved_tensors[2 + n:]
         mdt, tdt = _MMA[ctx.precision]
         cout, cin, k, _ = w.shape
         L = hip.lib()
@@ -222,18 +270,32 @@ class _ConvLevelsFn(torch.autograd.Function):
             Ws = (C.c_int * n)(*[xv.shape[2] for xv in xvs])
             ne = L.fcvsr_conv2d_wgrad_mfma_groups_scratch_elems(Bs, Hs, Ws, n, cin, cout, k, k)
             scratch = torch.empty(ne, dtype=torch.float32, device=w.device)
-            gw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=w.device)
+            sink = _grad_sink(w)
+            gw = sink if sink is not None else torch.empty((cout, cin, k, k), dtype=torch.float32, device=w.device)
             xd = (hip.View * n)(*[hip.view(xv) for xv in xvs])
             gd = (hip.View * n)(*[hip.view(gv) for gv in gvs])
-            hip.check(L.fcvsr_conv2d_wgrad_mfma_groups(xd, gd, Bs, Hs, Ws, n, k, k, k // 2, gw.data_ptr(), scratch.data_ptr(), ne, st),
-                      "fcvsr_conv2d_wgrad_mfma_groups")
+            L.fcvsr_wgrad_set_accumulate(1 if sink is not None else 0)
+            try:
+                hip.check(L.fcvsr_conv2d_wgrad_mfma_groups(xd, gd, Bs, Hs, Ws, n, k, k, k // 2, gw.data_ptr(), scratch.data_ptr(), ne, st),
+                          "fcvsr_conv2d_wgrad_mfma_groups")
+            finally:
+                L.fcvsr_wgrad_set_accumulate(0)
+            if sink is not None:
+                gw = None
         if ctx.has_bias and ctx.needs_input_grad[1]:
             ptrs = (C.c_void_p * n)(*[gv.data_ptr() for gv in gvs])
             npx = (C.c_longlong * n)(*[gv.numel() // cout for gv in gvs])
             ne = L.fcvsr_colsum_groups_scratch_elems(npx, n, cout)
             scratch = torch.empty(ne, dtype=torch.float32, device=w.device)
-            gb = torch.empty(cout, dtype=torch.float32, device=w.device)
-            hip.check(L.fcvsr_colsum_groups(ptrs, npx, n, cout, gb.data_ptr(), scratch.data_ptr(), ne, st), "fcvsr_colsum_groups")
+            bsink = _grad_sink(bias)
+            gb = bsink if bsink is not None else torch.empty(cout, dtype=torch.float32, device=w.device)
+            L.fcvsr_colsum_set_accumulate(1 if bsink is not None else 0)
+            try:
+                hip.check(L.fcvsr_colsum_groups(ptrs, npx, n, cout, gb.data_ptr(), scratch.data_ptr(), ne, st), "fcvsr_colsum_groups")
+            finally:
+                L.fcvsr_colsum_set_accumulate(0)
+            if bsink is not None:
+                gb = None
         return (gw, gb, None, None, None, *gxs)
 
 

@@ -19,6 +19,7 @@ import torch
 import torch.distributed as dist
 
 from .loss import charbonnier_loss
+from .ops import accumulate_into_grad
 
 
 def trainable_parameters(model: torch.nn.Module) -> List[Tuple[str, torch.nn.Parameter]]:
@@ -103,7 +104,8 @@ class TrainStep:
         self.allreduce.zero()                              # one fill: every .grad is a view of the flat buffer
         sr = self.model(lr_frames)
         loss = self.loss_fn(sr, hr)
-        loss.backward()
+        with accumulate_into_grad():                       # the HIP reductions add weight / bias gradients straight into it
+            loss.backward()
         return loss
 
     def reduce_and_update(self) -> None:
@@ -130,13 +132,15 @@ class TrainStep:
             with torch.cuda.stream(side):
                 for _ in range(2):
                     self.allreduce.zero()
-                    self.loss_fn(self.model(sx), sh).backward()
+                    with accumulate_into_grad():
+                        self.loss_fn(self.model(sx), sh).backward()
             torch.cuda.current_stream(lr_frames.device).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 self.allreduce.flat.zero_()                  # gradients accumulate into the static flat buffer
                 loss = self.loss_fn(self.model(sx), sh)
-                loss.backward()
+                with accumulate_into_grad():
+                    loss.backward()
             ent = self._graphs[key] = (graph, sx, sh, loss)
         graph, sx, sh, loss = ent
         sx.copy_(lr_frames)

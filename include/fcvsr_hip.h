@@ -168,6 +168,12 @@ int fcvsr_conv2d_wgrad_mfma_groups(const fcvsr_view* xs, const fcvsr_view* gys, 
  *   fcvsr_pool2_adjoint: g (B,H,W,C) -> (B,2H,2W,C), transposed 2x2 mean. */
 int fcvsr_up2_adjoint(const float* g, float* out, int B, int H, int W, int C, void* stream);
 int fcvsr_pool2_adjoint(const float* g, float* out, int B, int H, int W, int C, void* stream);
+/* Per-thread switches: while on, fcvsr_conv2d_wgrad / _mfma / _mfma_groups (dw) and fcvsr_colsum / _groups / fcvsr_wgrad_cout1 (out, dw)
+ * ADD their result to the destination instead of overwriting it.  The training step keeps every parameter gradient in one flat,
+ * pre-zeroed buffer and lets the reductions add straight into it (no AccumulateGrad addition per parameter and pass). */
+void fcvsr_wgrad_set_accumulate(int on);
+int fcvsr_wgrad_get_accumulate(void);
+void fcvsr_colsum_set_accumulate(int on);
 /* Diagnostic (FCVSR_RES_STAMPS=1 in the environment): copies the in-kernel cycle stamps the last resident-weight convolution
  * launch recorded for one workgroup, [wave 8][phase 64][slot 8] uint64, to host memory.  Not part of the data path. */
 int fcvsr_debug_res_stamps(void* host_out, size_t bytes);

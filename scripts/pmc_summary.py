@@ -29,11 +29,16 @@ def main(fetch_csv, write_csv, out=None):
         w_kib = wr.get(k, [0, 0.0, 0.0])[1]
         rows.append((us, k, n, f_kib * 1024 / n, w_kib * 1024 / max(1, wr.get(k, [1])[0]), us / n))
     rows.sort(reverse=True)
-    lines = ["# per-launch averages; read_x2 = gfx950 wide-stream correction of FETCH_SIZE",
-             f"{'kernel':64s} {'calls':>6s} {'avg_us':>9s} {'read_MB':>9s} {'read_x2_MB':>10s} {'write_MB':>9s} {'TB/s(x2)':>9s}"]
+    lines = ["# per-launch averages.  FETCH_SIZE on gfx950 reports 1/2 of the bytes of a wide (16 B/lane) coalesced stream and an uncalibrated",
+             "# fraction for other access widths (MI355X_MICROARCH.md, HBM): both the RAW and the x2-corrected read bytes are listed, with the",
+             "# rate each implies.  A row whose corrected rate exceeds 6.3 TB/s (what a streaming copy achieves) is flagged '!x2': the correction",
+             "# does not apply to that kernel's loads (narrower than 16 B per lane, or mostly L2 / Infinity-Cache hits) and the raw figure is the",
+             "# better estimate.",
+             f"{'kernel':64s} {'calls':>6s} {'avg_us':>9s} {'read_raw_MB':>11s} {'read_x2_MB':>10s} {'write_MB':>9s} {'TB/s(raw)':>9s} {'TB/s(x2)':>9s} flag"]
     for us, k, n, fb, wb, avg in rows[:30]:
         short = k if len(k) <= 64 else k[:61] + "..."
-        lines.append(f"{short:64s} {n:6d} {avg:9.1f} {fb/1e6:9.2f} {2*fb/1e6:10.2f} {wb/1e6:9.2f} {(2*fb+wb)/avg/1e6:9.2f}")
+        r_raw, r_x2 = (fb + wb) / avg / 1e6, (2 * fb + wb) / avg / 1e6
+        lines.append(f"{short:64s} {n:6d} {avg:9.1f} {fb/1e6:11.2f} {2*fb/1e6:10.2f} {wb/1e6:9.2f} {r_raw:9.2f} {r_x2:9.2f} {'!x2' if r_x2 > 6.3 else ''}")
     text = "\n".join(lines)
     print(text)
     if out:

@@ -156,3 +156,52 @@ def test_config4_full_model_reds4_shaped_streamed_over_two_ranks():
     ref_u8 = (ref.clamp(0, 1) * 255.0).numpy()[0]
     mse = float(((got[1][98].astype(np.float64) - ref_u8) ** 2).mean())
     assert 20 * np.log10(255 / np.sqrt(mse)) >= 45.0                # uint8 truncation of the harness bounds this (~ 51 dB for exact values)
+
+
+def _smooth_rgb(n, h, w, seed=3):
+    return torch.cat([_smooth_video(n, h, w, seed=seed + c) for c in range(3)], dim=1)          # (n, 3, h, w)
+
+
+def test_config2_rgb_twin_and_etc_at_a_vid4_shape_bf16():
+    """SURVEY 8(d) config 3 asks for the RGB twin at Vid4 shapes too, and round 2 ran GShiftNet_ETC only in f32 mode: the mmedit RGB
+    model FCVSR_SNet (21-channel input, 3x3 up-convs, 3-channel output) and the multi-window GShiftNet_ETC at the Vid4 'foliage' /
+    'walk' LR size 120x180, exact-f32 mode within 1e-4 of the CPU oracle and bf16 mode beyond 65 dB PSNR of it."""
+    from fcvsr_amd.arch.CVSR_freq import GShiftNet_ETC
+    from fcvsr_amd.arch.fcvsr_rgb import FCVSR_SNet
+    from fcvsr_amd.arch.schema import state_dict_shapes
+    from fcvsr_amd.weights import synthetic_state_dict
+    from oracle import fcvsr_oracle as O
+    H, W = 120, 180
+
+    def psnr_of(a, b):
+        mse = float(((a.double() - b.double()) * 255).pow(2).mean())
+        return 20 * np.log10(255 / np.sqrt(mse))
+
+    # RGB twin
+    sd = synthetic_state_dict(state_dict_shapes("FCVSR_SNet"))
+    model = FCVSR_SNet()
+    model.load_state_dict(sd)
+    model = model.cuda()
+    x = _smooth_rgb(7, H, W)[None]                                  # (1,7,3,H,W)
+    with torch.no_grad():
+        ref = O.forward(sd, x)
+        y32 = model(x.cuda()).cpu()
+        model.precision = "bf16"
+        y16 = model(x.cuda()).cpu()
+    assert y32.shape == (1, 3, 4 * H, 4 * W)
+    assert float((y32 - ref).abs().max()) <= 1e-4
+    assert psnr_of(y16, ref) >= 65.0, psnr_of(y16, ref)
+    del model
+    # multi-window model: 13 frames -> 7 SR frames + 7 bilinear bases
+    sd = synthetic_state_dict(state_dict_shapes("GShiftNet"))
+    etc = GShiftNet_ETC()
+    etc.load_state_dict(sd)
+    etc = etc.cuda()
+    xs = _smooth_video(13, H, W, seed=9)[None]                      # (1,13,1,H,W)
+    with torch.no_grad():
+        ref_seq, ref_up = O.forward_etc(sd, xs)
+        etc.precision = "bf16"
+        out_seq, x_up = etc(xs.cuda())
+    assert out_seq.shape == (1, 7, 1, 4 * H, 4 * W) and x_up.shape == out_seq.shape
+    assert float((x_up.cpu() - ref_up).abs().max()) <= 1e-5
+    assert psnr_of(out_seq.cpu(), ref_seq) >= 65.0, psnr_of(out_seq.cpu(), ref_seq)

@@ -20,6 +20,7 @@ import torch.nn.functional as F
 
 from ..engine import band_masks_half
 from .blocks import iac_both, prelu, rcb_tail, xscale
+from .fft import irfft_pair, spec_pack, split_bands
 from .ops import clear_packed_weights, conv2d, conv2d_levels
 
 Tensor = torch.Tensor
@@ -149,10 +150,13 @@ def _mgaa(c: _Ctx, key: str, x: Tensor, A: int) -> Tensor:
     B, C3, H, W = x.shape
     d = C3 // 3
     x1, x2, x3 = torch.split(x, d, dim=1)                            # (one cat in the backward instead of three zero-filled slices)
-    X = torch.fft.rfft2(x.contiguous(), norm="backward")             # one transform for the three groups
-    Xi, Xr = X.imag, X.real
-    spec = [torch.cat([Xi[:, g * d:(g + 1) * d], Xr[:, g * d:(g + 1) * d]], dim=1) for g in range(3)]   # imag first (:1456-1465)
-    x1f, x2f, x3f = spec
+    if c.fused_blocks:
+        # the library's NHWC rfft2: the [imag | real] packing of :1456-1465 is the kernel's output layout, no transposes, no cat
+        x1f, x2f, x3f = spec_pack(x1), spec_pack(x2), spec_pack(x3)
+    else:
+        X = torch.fft.rfft2(x.contiguous(), norm="backward")         # one transform for the three groups
+        Xi, Xr = X.imag, X.real
+        x1f, x2f, x3f = [torch.cat([Xi[:, g * d:(g + 1) * d], Xr[:, g * d:(g + 1) * d]], dim=1) for g in range(3)]   # imag first
     side = torch.cat([x1f, x3f], 0)                                  # (2B, 2d, H, Wf): forward direction, then backward
     mid = torch.cat([x2f, x2f], 0)
     off = (side - mid) + c.chain(key + ".convfuse", torch.cat([side, mid], 1), 3)
@@ -169,7 +173,10 @@ def _mgaa(c: _Ctx, key: str, x: Tensor, A: int) -> Tensor:
         t = _prelu(c.conv(blk + ".conv1", off), c.p[blk + ".relu.weight"])
         u = c.conv(blk + ".conv2", t)
         o = (c.ca(blk + ".CA", u) + u) * sim2
-        fld = torch.fft.irfft2(torch.complex(o[:, :2].contiguous(), o[:, 2:].contiguous()), s=(H, W), norm="backward")
+        if c.fused_blocks:
+            fld = irfft_pair(o, H, W)                                # channels [re0, re1 | im0, im1] -> two offset planes (:1497-1505)
+        else:
+            fld = torch.fft.irfft2(torch.complex(o[:, :2].contiguous(), o[:, 2:].contiguous()), s=(H, W), norm="backward")
         offs[0].append(fld[:B])
         offs[1].append(fld[B:])
     K = c.conv(key + ".F.1", c.conv(key + ".F.0", c.conv(key + ".conv_KP", x2)))
@@ -200,8 +207,11 @@ def _dev_masks(Q: int, H: int, W: int, dev) -> Tensor:
 def _mffr(c: _Ctx, key: str, x: Tensor, Q: int) -> Tensor:
     B, C, H, W = x.shape
     M = _dev_masks(Q, H, W, x.device)
-    X = torch.fft.rfft2(x.contiguous())
-    freq = [torch.fft.irfft2(X * M[n], s=(H, W)) for n in range(Q)][::-1]
+    if c.fused_blocks:
+        freq = split_bands(x, M)[::-1]                               # one forward transform, the Q masked inverse transforms in one call
+    else:
+        X = torch.fft.rfft2(x.contiguous())
+        freq = [torch.fft.irfft2(X * M[n], s=(H, W)) for n in range(Q)][::-1]
     s_f = torch.zeros_like(x)
     s_o = torch.zeros_like(x)
     for i in range(Q):

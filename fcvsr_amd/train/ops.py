@@ -54,7 +54,7 @@ class accumulate_into_grad:
 
 def _grad_sink(p: Optional[torch.Tensor]):
     """The parameter's `.grad` if the reductions may add into it in place, else None."""
-    if not ACCUMULATE_INTO_GRAD or p is None:
+    if not ACCUMULATE_INTO_GRAD or p is None or not p.is_leaf:
         return None
     g = p.grad
     if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or g.device != p.device:

@@ -179,6 +179,35 @@ __global__ __launch_bounds__(256) void wgrad_cout1_kernel(const float* __restric
   }
 }
 
+// Backward of the CorrBlock lookup (fcvsr_corr_lookup, reference :1279-1337): corr[c = i*n + j][y][x] = x1f[s] * x2f[s] / sqrt(C) at the
+// NHWC address s of flat element (y*Wf + x)*C + (y+j-r)*2 + (x+i-r) of the NCHW-contiguous product buffer.  For a fixed pixel the map
+// (i, j) -> s is one-to-one and different pixels own different I_p, so every s is written at most once: plain stores into zeroed
+// gradients, no atomics.  g: (B, H, xw-strip of Wf, gc) view; gx1 / gx2: dense NHWC (B, H*Wf, ps) zero-initialised.
+__global__ __launch_bounds__(256) void corr_lookup_bwd_kernel(const float* __restrict__ x1f, const float* __restrict__ x2f, long long ps, int B, int H,
+                                                              int Wf, int C, int radius, int xw, View g, float norm_div,
+                                                              float* __restrict__ gx1, float* __restrict__ gx2) {
+  const int n = 2 * radius + 1, nn = n * n;
+  const long long total = (long long)B * H * xw * nn;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int c = (int)(t % nn);
+  const long long pixg = t / nn;
+  const int x = (int)(pixg % xw);
+  const int y = (int)((pixg / xw) % H);
+  const int b = (int)(pixg / ((long long)xw * H));
+  const int i = c / n, j = c % n;
+  const int col = x + i - radius, row = y + j - radius;
+  if (col < 0 || col > 1 || row < 0 || row >= C / 2) return;
+  const long long HW = (long long)H * Wf;
+  const long long e = ((long long)y * Wf + x) * C + row * 2 + col;
+  const int ch = (int)(e / HW);
+  const long long pp = e % HW;
+  const long long src = ((long long)b * HW + pp) * ps + ch;
+  const float gg = g.p[(long long)b * g.sb + (long long)y * g.sy + (long long)x * g.sx + (long long)c * g.sc] / norm_div;
+  gx1[src] = gg * x2f[src];
+  gx2[src] = gg * x1f[src];
+}
+
 }  // namespace fcvsr
 
 using namespace fcvsr;
@@ -299,3 +328,18 @@ extern "C" int fcvsr_colsum_groups(const float* const* xs, const long long* npix
 }
 
 extern "C" void fcvsr_colsum_set_accumulate(int on) { g_colsum_accumulate = on ? 1 : 0; }
+
+/* backward of fcvsr_corr_lookup: g = dL/dcorr restricted to the first x_count columns (view with >= (2r+1)^2 channels), x1f / x2f as in
+ * the forward; gx1 / gx2: dense (B, H, Wf, pix_stride) f32 tensors that the caller has ZEROED (every element is written at most once) */
+extern "C" int fcvsr_corr_lookup_bwd(const float* x1f, const float* x2f, int64_t pix_stride, int B, int H, int Wf, int C, int radius, int x_count,
+                                     const fcvsr_view* g, float* gx1_zeroed, float* gx2_zeroed, void* stream) {
+  FCVSR_CHECK_ARG(x1f && x2f && g && g->ptr && gx1_zeroed && gx2_zeroed, "null pointer");
+  FCVSR_CHECK_ARG(B > 0 && H > 0 && Wf > 0 && C > 0 && C % 2 == 0 && radius >= 0 && pix_stride >= C, "bad sizes");
+  FCVSR_CHECK_ARG(g->c >= (2 * radius + 1) * (2 * radius + 1) && g->dtype == FCVSR_F32, "g: f32, >= (2r+1)^2 channels");
+  FCVSR_CHECK_ARG(x_count > 0 && x_count <= Wf, "x_count must be in [1, Wf]");
+  const long long total = (long long)B * H * x_count * (2 * radius + 1) * (2 * radius + 1);
+  hipLaunchKernelGGL(corr_lookup_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x1f, x2f, (long long)pix_stride, B, H, Wf, C,
+                     radius, x_count, to_view(*g), sqrtf((float)C), gx1_zeroed, gx2_zeroed);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}

@@ -213,12 +213,12 @@ __global__ __launch_bounds__(256) void rcbt_bwd2_kernel(const float* __restrict_
 }
 
 // out[i] = sum_j in[j][i] in row order (final stage of the weight-gradient sums): n elements, rows rows
-__global__ __launch_bounds__(256) void rcbt_rowsum_kernel(const float* __restrict__ in, int rows, int n, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void rcbt_rowsum_kernel(const float* __restrict__ in, int rows, int n, float* __restrict__ out, int accumulate) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float s = 0.f;
   for (int j = 0; j < rows; ++j) s += in[(long long)j * n + i];
-  out[i] = s;
+  out[i] = accumulate ? out[i] + s : s;
 }
 
 // Adjoint of the x2 bilinear up-sampling of fcvsr_xscale (align_corners = False, source index clamped at 0 and at the last row /
@@ -300,11 +300,11 @@ extern "C" int fcvsr_rcbt_forward(const float* r, const float* z, const float* w
   return 0;
 }
 
-/* backward: g = dL/dout; writes gr (dL/dr; dL/dz = g), dwmask[64], dw1[64*64], dw2[64*64];
+/* backward: g = dL/dout; writes gr (dL/dr; dL/dz = g) and writes (accumulate = 0) or adds to (1) dwmask[64], dw1[64*64], dw2[64*64];
  * scratch >= B * nblk * 64 + B * 65 + 2 * B * 4096 floats */
 extern "C" int fcvsr_rcbt_backward(const float* r, const float* g, const float* wmask, const float* w1, const float* w2, const float* stats,
                                    float slope, int B, int HW, int C, float* gr, float* dwmask, float* dw1, float* dw2, float* scratch,
-                                   long long scratch_elems, void* stream) {
+                                   long long scratch_elems, int accumulate, void* stream) {
   FCVSR_CHECK_ARG(r && g && wmask && w1 && w2 && stats && gr && dwmask && dw1 && dw2 && scratch, "null pointer");
   FCVSR_CHECK_ARG(C == kTC, "64 channels");
   const int nblk = (HW + kTPB - 1) / kTPB;
@@ -320,9 +320,9 @@ extern "C" int fcvsr_rcbt_backward(const float* r, const float* g, const float* 
   hipLaunchKernelGGL(rcbt_bwd1_kernel, dim3(nblk, B), dim3(256), 0, st, r, g, stats, slope, HW, part);
   hipLaunchKernelGGL(rcbt_bwdmid_kernel, dim3(B), dim3(64), 0, st, part, nblk, w1, w2, stats, slope, bst, dw1b, dw2b);
   hipLaunchKernelGGL(rcbt_bwd2_kernel, dim3(nblk, B), dim3(256), 0, st, r, g, wmask, stats, bst, slope, HW, gr, part);
-  hipLaunchKernelGGL(rcbt_rowsum_kernel, dim3(1), dim3(256), 0, st, part, B * nblk, kTC, dwmask);
-  hipLaunchKernelGGL(rcbt_rowsum_kernel, dim3(kTC * kTC / 256), dim3(256), 0, st, dw1b, B, kTC * kTC, dw1);
-  hipLaunchKernelGGL(rcbt_rowsum_kernel, dim3(kTC * kTC / 256), dim3(256), 0, st, dw2b, B, kTC * kTC, dw2);
+  hipLaunchKernelGGL(rcbt_rowsum_kernel, dim3(1), dim3(256), 0, st, part, B * nblk, kTC, dwmask, accumulate);
+  hipLaunchKernelGGL(rcbt_rowsum_kernel, dim3(kTC * kTC / 256), dim3(256), 0, st, dw1b, B, kTC * kTC, dw1, accumulate);
+  hipLaunchKernelGGL(rcbt_rowsum_kernel, dim3(kTC * kTC / 256), dim3(256), 0, st, dw2b, B, kTC * kTC, dw2, accumulate);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

@@ -28,26 +28,34 @@ class _RcbTailFn(torch.autograd.Function):
         hip.check(L.fcvsr_rcbt_forward(rv.data_ptr(), zv.data_ptr(), wm.data_ptr(), a1.data_ptr(), a2.data_ptr(), slope, B, H * W, Cn,
                                        out.data_ptr(), stats.data_ptr(), scratch.data_ptr(), scratch.numel(), hip.stream_ptr()),
                   "fcvsr_rcbt_forward")
-        ctx.save_for_backward(rv, wm, a1, a2, stats)
+        ctx.save_for_backward(rv, wm, a1, a2, stats, wmask, w1, w2)
         ctx.slope, ctx.shapes = slope, (wmask.shape, w1.shape, w2.shape)
         return out.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, g):
-        rv, wm, a1, a2, stats = ctx.saved_tensors
+        rv, wm, a1, a2, stats, p_wm, p_w1, p_w2 = ctx.saved_tensors
         gv = _nhwc(g.float())
         B, H, W, Cn = rv.shape
         L = hip.lib()
         nblk = L.fcvsr_rcbt_nblk(H * W)
         gr = torch.empty_like(rv)
-        dwm = torch.empty(Cn, dtype=torch.float32, device=rv.device)
-        dw1 = torch.empty(Cn * Cn, dtype=torch.float32, device=rv.device)
-        dw2 = torch.empty(Cn * Cn, dtype=torch.float32, device=rv.device)
+        from .ops import _grad_sink
+        sinks = [_grad_sink(p) for p in (p_wm, p_w1, p_w2)]
+        inplace = all(s_ is not None for s_ in sinks)                      # add into the flat gradient buffer (ops.accumulate_into_grad)
+        if inplace:
+            dwm, dw1, dw2 = sinks
+        else:
+            dwm = torch.empty(Cn, dtype=torch.float32, device=rv.device)
+            dw1 = torch.empty(Cn * Cn, dtype=torch.float32, device=rv.device)
+            dw2 = torch.empty(Cn * Cn, dtype=torch.float32, device=rv.device)
         n = B * nblk * Cn + B * (Cn + 1) + 4 + 2 * B * Cn * Cn
         scratch = torch.empty(n, dtype=torch.float32, device=rv.device)
         hip.check(L.fcvsr_rcbt_backward(rv.data_ptr(), gv.data_ptr(), wm.data_ptr(), a1.data_ptr(), a2.data_ptr(), stats.data_ptr(), ctx.slope,
                                         B, H * W, Cn, gr.data_ptr(), dwm.data_ptr(), dw1.data_ptr(), dw2.data_ptr(), scratch.data_ptr(), n,
-                                        hip.stream_ptr()), "fcvsr_rcbt_backward")
+                                        int(inplace), hip.stream_ptr()), "fcvsr_rcbt_backward")
+        if inplace:
+            return gr.permute(0, 3, 1, 2), g, None, None, None, None
         s0, s1, s2 = ctx.shapes
         return gr.permute(0, 3, 1, 2), g, dwm.reshape(s0), dw1.reshape(s1), dw2.reshape(s2), None
 
@@ -213,3 +221,44 @@ def xscale(x: torch.Tensor, R: torch.Tensor, r_scale: float, dn=None, up=None) -
     if not x.is_cuda:
         raise RuntimeError("fcvsr_amd.train.blocks needs device tensors (the HIP path has no CPU fallback)")
     return _XscaleFn.apply(x, R, float(r_scale), dn, up)
+
+
+class _CorrLookupFn(torch.autograd.Function):
+    """CorrBlock lookup on the un-updated integer grid (reference :1279-1337): a bounds-checked gather from the raw-viewed
+    product x1f * x2f / sqrt(C), non-zero only on the columns x <= radius + 1.  fcvsr_corr_lookup on the strip forward, one scatter-free
+    kernel backward (was: product, NCHW copy, index gather, mask multiply and an index_put backward with a device sort)."""
+
+    @staticmethod
+    def forward(ctx, x1f, x2f, radius):
+        import ctypes as C_
+        a, b = _nhwc(x1f.float()), _nhwc(x2f.float())
+        B, H, Wf, Cn = a.shape
+        n = 2 * radius + 1
+        out = torch.zeros((B, H, Wf, n * n), dtype=torch.float32, device=a.device)
+        xw = min(Wf, radius + 2)
+        ov = hip.view(out)
+        hip.check(hip.lib().fcvsr_corr_lookup(a.data_ptr(), b.data_ptr(), Cn, B, H, Wf, Cn, radius, xw, C_.byref(ov), hip.stream_ptr()),
+                  "fcvsr_corr_lookup")
+        ctx.save_for_backward(a, b)
+        ctx.radius, ctx.xw = radius, xw
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes as C_
+        a, b = ctx.saved_tensors
+        B, H, Wf, Cn = a.shape
+        gv = g.float().permute(0, 2, 3, 1)
+        if gv.stride(3) != 1:
+            gv = gv.contiguous()
+        ga, gb = torch.zeros_like(a), torch.zeros_like(b)
+        gview = hip.view(gv)
+        hip.check(hip.lib().fcvsr_corr_lookup_bwd(a.data_ptr(), b.data_ptr(), Cn, B, H, Wf, Cn, ctx.radius, ctx.xw, C_.byref(gview), ga.data_ptr(),
+                                                  gb.data_ptr(), hip.stream_ptr()), "fcvsr_corr_lookup_bwd")
+        return ga.permute(0, 3, 1, 2), gb.permute(0, 3, 1, 2), None
+
+
+def corr_lookup(x1f: torch.Tensor, x2f: torch.Tensor, radius: int = 4) -> torch.Tensor:
+    if not x1f.is_cuda:
+        raise RuntimeError("fcvsr_amd.train.blocks needs device tensors (the HIP path has no CPU fallback)")
+    return _CorrLookupFn.apply(x1f, x2f, radius)

@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from ..engine import band_masks_half
-from .blocks import iac_both, prelu, rcb_tail, xscale
+from .blocks import corr_lookup, iac_both, prelu, rcb_tail, xscale
 from .fft import irfft_pair, spec_pack, split_bands
 from .ops import clear_packed_weights, conv2d, conv2d_levels
 
@@ -161,7 +161,7 @@ def _mgaa(c: _Ctx, key: str, x: Tensor, A: int) -> Tensor:
     mid = torch.cat([x2f, x2f], 0)
     off = (side - mid) + c.chain(key + ".convfuse", torch.cat([side, mid], 1), 3)
     sim = c.chain(key + ".convcrt", x2f, 2)
-    corr = _corr_lookup(x1f, x2f)                                   # forward pair only, reused for both directions (:1487-1488)
+    corr = corr_lookup(x1f, x2f) if c.fused_blocks else _corr_lookup(x1f, x2f)   # forward pair only, reused for both directions (:1487-1488)
     flow0 = torch.zeros(2 * B, 2, H, x1f.shape[-1], dtype=x.dtype, device=x.device)
     t = c.conv_padded(key + ".convcorr.0", [off, torch.cat([corr, corr], 0), flow0], act="relu")       # 211 -> 64 (:1379-1385)
     t = conv2d(t, c.p[key + ".convcorr.2.weight"], None, 1, c.precision, "relu")

@@ -135,7 +135,10 @@ int fcvsr_rcbt_forward(const float* r, const float* z, const float* wmask, const
                        int C, float* out, float* stats, float* scratch, long long scratch_elems, void* stream);
 int fcvsr_rcbt_backward(const float* r, const float* g, const float* wmask, const float* w1, const float* w2, const float* stats,
                         float slope, int B, int HW, int C, float* gr, float* dwmask, float* dw1, float* dw2, float* scratch,
-                        long long scratch_elems, void* stream);
+                        long long scratch_elems, int accumulate /* 1: dwmask / dw1 / dw2 += */, void* stream);
+/* backward of fcvsr_corr_lookup: g = dL/dcorr on the first x_count columns; gx1 / gx2 dense (B,H,Wf,pix_stride), ZEROED by the caller */
+int fcvsr_corr_lookup_bwd(const float* x1f, const float* x2f, int64_t pix_stride, int B, int H, int Wf, int C, int radius, int x_count,
+                          const fcvsr_view* g, float* gx1_zeroed, float* gx2_zeroed, void* stream);
 long long fcvsr_colsum_groups_scratch_elems(const long long* npix, int n_groups, int C);
 int fcvsr_colsum_groups(const float* const* xs, const long long* npix, int n_groups, int C, float* out, float* scratch,
                         long long scratch_elems, void* stream);   /* column sums of 1..3 matrices added together, one ordered second stage */

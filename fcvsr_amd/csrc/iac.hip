@@ -293,6 +293,11 @@ constexpr int kKtRow = 3 * kJC + 8;                   // halfwords per pixel row
 #ifndef FCVSR_IAC_PIPE
 #define FCVSR_IAC_PIPE 1
 #endif
+// Ablation builds (-DFCVSR_IAC_ABL=bits, one library per value run through scripts/ab_lib.sh; profiles/r03_iac_ablation.txt):
+// 1 no gather loads, 2 no SAC arithmetic / LDS reads, 4 no predictor GEMM, 8 no stores, 16 no offset loads.  0 in every shipped build.
+#ifndef FCVSR_IAC_ABL
+#define FCVSR_IAC_ABL 0
+#endif
 // Persistent workgroups (the host launches two per CU): each walks a contiguous run of tiles, so the predictor weights of
 // its waves (FK: 4 or 8 MFMA A-fragments) and the bias are fetched once per workgroup instead of once per tile (24 KB per
 // tile was a quarter of what a tile pulled through L2), and consecutive tiles of a workgroup share their halo columns in L1.
@@ -360,6 +365,7 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
     const long long osb = d1 ? a.d[1].off.sb : a.d[0].off.sb, osy = d1 ? a.d[1].off.sy : a.d[0].off.sy;
     const long long osx = d1 ? a.d[1].off.sx : a.d[0].off.sx, osc = d1 ? a.d[1].off.sc : a.d[0].off.sc;
     const float* op = op0 + (long long)bb * osb + (long long)gy * osy + (long long)gx * osx;
+    if (FCVSR_IAC_ABL & 16) return make_float2(0.25f, 0.25f);
     return make_float2(op[0], op[osc]);
   };
   float2 off_next = make_float2(0.f, 0.f);
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
   // The 12 pixel fragments are requested here, with the offsets; the MFMAs run after the first direction's taps have been
   // issued, so the gather latency hides behind them.
   uint4 kf[3][4];
-  if (FK) {
+  if (FK && !(FCVSR_IAC_ABL & 4)) {
     const uint16_t* k0p = reinterpret_cast<const uint16_t*>(a.k0.p) + (long long)b * a.k0.sb + hh * 8;
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
@@ -512,7 +518,8 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
       const int src = dir * 32 + it * 8 + (lane >> 3);  // the lane that owns (dir, it, this lane's pixel)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        tap[dir][it][q] = ld_p8<ADT>(pb, __shfl(my_eo[q], src));
+        if (FCVSR_IAC_ABL & 1) tap[dir][it][q] = Pack8<ADT>{};
+        else tap[dir][it][q] = ld_p8<ADT>(pb, __shfl(my_eo[q], src));
       }
     }
   };
@@ -555,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
         unpack_k24<KDT>(j < 2 ? kin[j] : khal, k);
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tt = 0; tt < 3; ++tt) {
+        for (int tt = 0; tt < ((FCVSR_IAC_ABL & 2) ? 0 : 3); ++tt) {
           const int sp = (y + tt) * kIHX + hx;
           const float4 va = *reinterpret_cast<const float4*>(s_s + rec(sp, 0)), vb = *reinterpret_cast<const float4*>(s_s + rec(sp, 1));
           const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
@@ -580,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
         unpack8<ADT>(fpk[dir][j], f);
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tt = 0; tt < 3; ++tt) {
+        for (int tt = 0; tt < ((FCVSR_IAC_ABL & 2) ? 0 : 3); ++tt) {
           const int vp = y * kIHX + x + tt;
           const float4 va = *reinterpret_cast<const float4*>(v_s + rec(vp, 0)), vb = *reinterpret_cast<const float4*>(v_s + rec(vp, 1));
           const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
@@ -592,13 +599,14 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
           acc[c] += f[c];
           acc[c] = acc[c] >= 0.f ? acc[c] : acc[c] * slope;
         }
-        st_p8<ADT>(dst.p, (long long)b * dst.sb + (long long)gy * dst.sy + (long long)gx * dst.sx + c0, acc);
+        if (!(FCVSR_IAC_ABL & 8) || acc[0] == 1234.5f)
+          st_p8<ADT>(dst.p, (long long)b * dst.sb + (long long)gy * dst.sy + (long long)gx * dst.sx + c0, acc);
       }
     }
   };
 
   issue_taps(0);
-  if (FK) {                                            // the predicted kernels of the lane's pixels: LDS -> registers, once
+  if (FK && !(FCVSR_IAC_ABL & 4)) {                                            // the predicted kernels of the lane's pixels: LDS -> registers, once
     predictor_gemm();                                  // kf requested before the taps: in flight since the tile began
     __syncthreads();                                   // GEMM results of all four waves are in kt_s
 #pragma unroll

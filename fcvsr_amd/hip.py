@@ -141,6 +141,11 @@ SIGNATURES = {
     "fcvsr_rcbt_stat_elems": [],
     "fcvsr_rcbt_forward": [_VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, C.c_longlong, _VP],
     "fcvsr_rcbt_backward": [_VP, _VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, C.c_longlong, _I, _VP],
+    "fcvsr_divenh_band_nblk": [_I],
+    "fcvsr_divenh_band_stat_elems": [_I],
+    "fcvsr_divenh_band_forward": [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, C.c_longlong, _VP],
+    "fcvsr_divenh_band_backward": [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
+                                   C.c_longlong, _I, _VP],
     "fcvsr_corr_lookup_bwd": [_VP, _VP, _I64, _I, _I, _I, _I, _I, _I, _PV, _VP, _VP, _VP],
 }
 _RESTYPES = {"fcvsr_wgrad_set_accumulate": None, "fcvsr_colsum_set_accumulate": None, "fcvsr_last_error": C.c_char_p, "fcvsr_last_conv_kernel": C.c_char_p, "fcvsr_conv2d_wgrad_scratch_elems": C.c_longlong,

@@ -67,6 +67,66 @@ def rcb_tail(r: torch.Tensor, z: torch.Tensor, wmask: torch.Tensor, w1: torch.Te
     return _RcbTailFn.apply(r, z, wmask, w1, w2, float(slope))
 
 
+class _DivEnhBandFn(torch.autograd.Function):
+    """One DivEnh band (i >= 1) of MultiFreq_Refinment and its running sums (reference CVSR_freq.py:2104-2133 at :2201-2254):
+    (Sf, So) -> (Sf + f, So + e1 CA(e1) + e2 CA(e2)), three forward and seven backward launches (train_mffr.hip)."""
+
+    @staticmethod
+    def forward(ctx, f, sf, so, a, b, w1, w2):
+        fv, sfv, sov = (_nhwc(t.float()) for t in (f, sf, so))
+        B, H, W, Cn = fv.shape
+        L = hip.lib()
+        nblk = L.fcvsr_divenh_band_nblk(H * W)
+        sf_out, so_out = torch.empty_like(fv), torch.empty_like(fv)
+        stats = torch.empty((B, L.fcvsr_divenh_band_stat_elems(Cn)), dtype=torch.float32, device=fv.device)
+        scratch = torch.empty(B * nblk * 2 * Cn, dtype=torch.float32, device=fv.device)
+        av, bv, a1, a2 = (t.detach().float().contiguous() for t in (a, b, w1, w2))
+        hip.check(L.fcvsr_divenh_band_forward(fv.data_ptr(), sfv.data_ptr(), sov.data_ptr(), av.data_ptr(), bv.data_ptr(), a1.data_ptr(),
+                                              a2.data_ptr(), B, H * W, Cn, sf_out.data_ptr(), so_out.data_ptr(), stats.data_ptr(),
+                                              scratch.data_ptr(), scratch.numel(), hip.stream_ptr()), "fcvsr_divenh_band_forward")
+        ctx.save_for_backward(fv, sfv, sov, av, bv, a1, a2, stats, a, b, w1, w2)
+        return sf_out.permute(0, 3, 1, 2), so_out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gsf, gso):
+        fv, sfv, sov, av, bv, a1, a2, stats, p_a, p_b, p_w1, p_w2 = ctx.saved_tensors
+        B, H, W, Cn = fv.shape
+        CR = Cn // 16
+        hv = _nhwc(gsf.float()) if gsf is not None else torch.zeros_like(fv)
+        ov = _nhwc(gso.float()) if gso is not None else torch.zeros_like(fv)
+        L = hip.lib()
+        nblk = L.fcvsr_divenh_band_nblk(H * W)
+        gf, gsf_o, gso_o = torch.empty_like(fv), torch.empty_like(fv), torch.empty_like(fv)
+        from .ops import _grad_sink
+        sinks = [_grad_sink(p) for p in (p_a, p_b, p_w1, p_w2)]
+        inplace = all(s_ is not None for s_ in sinks)
+        if inplace:
+            ga, gb, dw1, dw2 = sinks
+        else:
+            ga = torch.empty(Cn, dtype=torch.float32, device=fv.device)
+            gb = torch.empty(Cn, dtype=torch.float32, device=fv.device)
+            dw1 = torch.empty(CR * Cn, dtype=torch.float32, device=fv.device)
+            dw2 = torch.empty(Cn * CR, dtype=torch.float32, device=fv.device)
+        n = B * nblk * 2 * Cn + 2 * B * Cn + 2 * B * Cn * CR
+        scratch = torch.empty(n, dtype=torch.float32, device=fv.device)
+        hip.check(L.fcvsr_divenh_band_backward(fv.data_ptr(), sfv.data_ptr(), sov.data_ptr(), av.data_ptr(), bv.data_ptr(), a1.data_ptr(),
+                                               a2.data_ptr(), stats.data_ptr(), hv.data_ptr(), ov.data_ptr(), B, H * W, Cn, gf.data_ptr(),
+                                               gsf_o.data_ptr(), gso_o.data_ptr(), ga.data_ptr(), gb.data_ptr(), dw1.data_ptr(),
+                                               dw2.data_ptr(), scratch.data_ptr(), n, int(inplace), hip.stream_ptr()),
+                  "fcvsr_divenh_band_backward")
+        outs = tuple(t.permute(0, 3, 1, 2) for t in (gf, gsf_o, gso_o))
+        if inplace:
+            return outs + (None, None, None, None)
+        return outs + (ga.reshape(p_a.shape), gb.reshape(p_b.shape), dw1.reshape(p_w1.shape), dw2.reshape(p_w2.shape))
+
+
+def divenh_band(f, sf, so, a, b, w1, w2):
+    """(Sf', So') of one DivEnh band i >= 1 for device tensors (B,C,H,W), C in {32, 64}; a, b: C values; w1 (C/16,C,1,1), w2 (C,C/16,1,1)."""
+    if not f.is_cuda:
+        raise RuntimeError("fcvsr_amd.train.blocks needs device tensors (the HIP path has no CPU fallback)")
+    return _DivEnhBandFn.apply(f, sf, so, a, b, w1, w2)
+
+
 class _IacFn(torch.autograd.Function):
     """IAC of BOTH alignment directions (reference CVSR_freq.py:1230-1250 called at :1524-1545): A iterations of
     LeakyReLU(SAC_h(SAC_v(flow_warp(feat, off_i), K1_i), K1_i) + feat_in) per direction, the two directions sharing the predicted

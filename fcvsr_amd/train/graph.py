@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from ..engine import band_masks_half
-from .blocks import corr_lookup, iac_both, prelu, rcb_tail, xscale
+from .blocks import corr_lookup, divenh_band, iac_both, prelu, rcb_tail, xscale
 from .fft import irfft_pair, spec_pack, split_bands
 from .ops import clear_packed_weights, conv2d, conv2d_levels
 
@@ -220,6 +220,10 @@ def _mffr(c: _Ctx, key: str, x: Tensor, Q: int) -> Tensor:
         f = freq[i]
         if i == 0:
             o = c.ca(blk + ".ca", 0.2 * a * (f - f.mean(dim=(2, 3), keepdim=True)) * f + b * f)
+        elif c.fused_blocks and C in (32, 64):
+            s_f, s_o = divenh_band(f, s_f, s_o, c.p[blk + ".a"], c.p[blk + ".b"], c.p[blk + ".ca.conv_du.0.weight"],
+                                   c.p[blk + ".ca.conv_du.2.weight"])
+            continue
         else:
             t = f - s_f + 0.2 * s_o
             o = c.ca(blk + ".ca", 0.2 * a * t * f + b * f) + c.ca(blk + ".ca", 0.2 * a * s_o * f + b * f)

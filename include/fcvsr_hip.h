@@ -136,6 +136,20 @@ int fcvsr_rcbt_forward(const float* r, const float* z, const float* wmask, const
 int fcvsr_rcbt_backward(const float* r, const float* g, const float* wmask, const float* w1, const float* w2, const float* stats,
                         float slope, int B, int HW, int C, float* gr, float* dwmask, float* dw1, float* dw2, float* scratch,
                         long long scratch_elems, int accumulate /* 1: dwmask / dw1 / dw2 += */, void* stream);
+
+/* One DivEnh band (i >= 1) of MultiFreq_Refinment with its running sums, forward and backward (training path; reference
+ * CVSR_freq.py:2104-2133 applied at :2201-2254 with CALayer :1812-1828):  t = f - Sf + 0.2 So, e1 = (0.2 a t + b) f, e2 = (0.2 a So + b) f,
+ * So' = So + e1 CA(e1) + e2 CA(e2), Sf' = Sf + f.  Tensors dense (B, HW, C) f32, C in {32, 64}; w1 (C/16, C), w2 (C, C/16).
+ * forward scratch >= B * nblk * 2C floats; backward scratch >= B * nblk * 2C + 2BC + 2BC(C/16) floats; stats = B * stat_elems(C) floats. */
+int fcvsr_divenh_band_nblk(int HW);
+int fcvsr_divenh_band_stat_elems(int C);
+int fcvsr_divenh_band_forward(const float* f, const float* sf, const float* so, const float* a, const float* b, const float* w1,
+                              const float* w2, int B, int HW, int C, float* sf_out, float* so_out, float* stats, float* scratch,
+                              long long scratch_elems, void* stream);
+int fcvsr_divenh_band_backward(const float* f, const float* sf, const float* so, const float* a, const float* b, const float* w1,
+                               const float* w2, const float* stats, const float* gsf, const float* gso, int B, int HW, int C, float* gf,
+                               float* gsf_out, float* gso_out, float* ga, float* gb, float* dw1, float* dw2, float* scratch,
+                               long long scratch_elems, int accumulate, void* stream);
 /* backward of fcvsr_corr_lookup: g = dL/dcorr on the first x_count columns; gx1 / gx2 dense (B,H,Wf,pix_stride), ZEROED by the caller */
 int fcvsr_corr_lookup_bwd(const float* x1f, const float* x2f, int64_t pix_stride, int B, int H, int Wf, int C, int radius, int x_count,
                           const fcvsr_view* g, float* gx1_zeroed, float* gx2_zeroed, void* stream);

@@ -92,9 +92,9 @@ class TrainStep:
         self.names = [n for n, _ in named]
         params = [p for _, p in named]
         # reference defaults: Adam(lr=1e-4, weight_decay=1e-5) (train_LD_freqCVSR_S_22.py:35,42,204)
-        # on the device: torch's single-launch multi-tensor Adam (same update rule; the default is ~10 launches per step)
-        self.optimizer = optimizer or torch.optim.Adam(params, lr=lr, weight_decay=weight_decay,
-                                                       fused=True if params and params[0].is_cuda else None)
+        # (torch's fused=True Adam does not advance the parameters' version counters, which the inference engine's packed-weight
+        # cache is keyed on: the default multi-tensor implementation stays)
+        self.optimizer = optimizer or torch.optim.Adam(params, lr=lr, weight_decay=weight_decay)
         self.loss_fn = loss_fn
         self.allreduce = FlatGradAllReduce(params, reduce_op, group)
 

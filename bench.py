@@ -466,6 +466,28 @@ def main():
                     "conv_kernels_ms_per_step": {kn: round(v, 3) for kn, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])},
                     "all_conv_kernels": {"tflops": round(cls_fl / (cls_ms * 1e-3) / 1e12, 3) if cls_ms > 0 else 0.0,
                                          "launches_per_step": len(cls), "ms_per_step": round(cls_ms, 3)}}
+        if args.precision != "f32":
+            # Context, not the price: what the vendor's own GEMM (hipBLASLt through torch.matmul, 8192^3 in the same 16-bit type)
+            # sustains on THIS box at its power limit.  `peak` / `frac` above stay on the data-sheet figure.
+            try:
+                mdt = torch.bfloat16 if args.precision == "bf16" else torch.float16
+                ga = torch.randn(8192, 8192, device=dev, dtype=mdt)
+                gb = torch.randn(8192, 8192, device=dev, dtype=mdt)
+                gc = torch.empty(8192, 8192, device=dev, dtype=mdt)
+                for _ in range(3):
+                    torch.matmul(ga, gb, out=gc)
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record()
+                for _ in range(10):
+                    torch.matmul(ga, gb, out=gc)
+                g1.record()
+                torch.cuda.synchronize()
+                vt = 10 * 2.0 * 8192.0 ** 3 / (g0.elapsed_time(g1) * 1e-3) / 1e12
+                roofline["vendor_gemm"] = {"what": "hipBLASLt 8192x8192x8192 via torch.matmul, same box, same dtype", "tflops": round(vt, 1),
+                                           "frac_of_peak": round(vt / peak, 4), "achieved_over_vendor_gemm": round(ach / vt, 4)}
+                del ga, gb, gc
+            except Exception as e:                             # calibration only: never fails the bench
+                roofline["vendor_gemm"] = {"error": repr(e)[:200]}
 
     cpu = None
     parity = None

@@ -14,6 +14,8 @@
 
 namespace fcvsr {
 
+typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
+
 constexpr int kIY = 4, kIX = 16, kIC = 32;            // tile rows, cols, channels per workgroup
 constexpr int kIHX = kIX + 2, kIHY = kIY + 2;
 
@@ -638,6 +640,314 @@ __global__ __launch_bounds__(256, 2) void iac_step64_kernel(IacArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Second form of the fused-predictor step (round 3; 16-bit activations, both directions): the predicted kernels never touch
+// LDS.  Lane (n, q) = (l & 15, l >> 4) of wave w owns pixel (row w, column n) of the tile's 4 x 16 "v domain" (14 interior
+// columns + one halo column each side) and 16 consecutive channels q*16 .. q*16+15.  The predictor GEMM runs per wave as
+// 12 M-tiles of v_mfma_f32_16x16x32 (A = weight rows, B = the row's 16 pixels of k0): with the weight rows permuted so that
+// M-tile (tap t, block cb) row r is channel (r >> 2) * 16 + cb * 4 + (r & 3), the accumulator of lane (n, q) IS the kernel of
+// its pixel for channels q*16 + cb*4 .. +3 and tap t.  No kernel tile in LDS, no transposing barriers, 8 instead of 48
+// registers of predictor input, 24 instead of 36 registers of kernels; v overlays s (the vertical results wait in registers
+// across one barrier): 49.9 KB of LDS and < 168 VGPRs = three workgroups per CU.  s / v records are 64 floats in 16 slots of
+// 16 bytes, slot index XOR (pixel & 15): the warp's stores (8 lanes x 2 slots per pixel) and the SAC reads (16 pixels x 4
+// slots per instruction) both spread evenly over the banks.
+constexpr int kQX = 14, kQVX = 16, kQY = 4, kQSY = kQY + 2;
+constexpr int kQNS = kQSY * kQVX, kQNV = kQY * kQVX;     // 96 warped pixels, 64 vertical results per tile
+
+template <bool BF16>
+__device__ __forceinline__ f32x4v_t mfma16x(uint4 a, uint4 b, f32x4v_t c) {
+  if (BF16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+struct Iac2Args {        // compact: both directions share every stride (host-checked), 32-bit offsets inside one image
+  const uint16_t* prev[2];
+  const float* off[2];
+  const uint16_t* fin[2];
+  uint16_t* dst[2];
+  const uint16_t* k0;
+  const uint16_t* wk;
+  const float* kbias;
+  long long prev_sb, off_sb, fin_sb, dst_sb, k0_sb;
+  int prev_sy, prev_sx, off_sy, off_sx, off_sc, fin_sy, fin_sx, dst_sy, dst_sx, k0_sy, k0_sx;
+  float slope;
+  int H, W, tiles_x, tiles_y, ntiles;
+};
+
+#ifndef FCVSR_IAC2_WGS
+#define FCVSR_IAC2_WGS 3
+#endif
+#ifndef FCVSR_IAC2_EARLY
+#define FCVSR_IAC2_EARLY 2
+#endif
+template <int KDT, int ADT>
+__global__ __launch_bounds__(256, FCVSR_IAC2_WGS) void iac_fused2_kernel(Iac2Args a) {
+  static_assert(ADT != FCVSR_F32 && KDT != FCVSR_F32, "16-bit form");
+  constexpr bool BF = KDT == FCVSR_BF16;
+  constexpr int ND = 2, NP = kQNS / 32;                  // 3 gather passes of 32 pixel slots
+  __shared__ __align__(16) float s_s[kQNS * kJC];        // 24,576 B; v = records 0..63
+  __shared__ __align__(16) uint16_t w_s[3 * kJC * kJC];  // 24,576 B, 16-byte segments XOR (row & 7)
+  __shared__ __align__(16) float kb_s[3 * kJC];
+  float* const v_s = s_s;
+  const float slope = a.slope;
+  const int H = a.H, W = a.W, tiles_x = a.tiles_x, tiles_y = a.tiles_y;
+  int t_begin, t_end;
+  {
+    const int g = blockIdx.x, nwg = gridDim.x, qq = nwg >> 3, rr = nwg & 7, xcd = g & 7, loc = g >> 3;
+    const int ci = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;
+    t_begin = (int)((long long)ci * a.ntiles / nwg);
+    t_end = (int)((long long)(ci + 1) * a.ntiles / nwg);
+  }
+  {                                                      // predictor weights (rows permuted) and bias: once per workgroup
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 3 * kJC * kJC / 8 / 256; ++i) {
+      const int idx = tid + 256 * i, R = idx >> 3, seg = idx & 7;
+      const int mt = R >> 4, r = R & 15, tp = mt >> 2, cb = mt & 3;
+      const int orig = ((r >> 2) * 16 + cb * 4 + (r & 3)) * 3 + tp;
+      *reinterpret_cast<uint4*>(w_s + R * kJC + ((seg ^ (R & 7)) << 3)) = *reinterpret_cast<const uint4*>(a.wk + orig * kJC + seg * 8);
+    }
+    if (tid < 3 * kJC) {
+      const int mt = tid >> 4, r = tid & 15, tp = mt >> 2, cb = mt & 3;
+      kb_s[tid] = a.kbias[((r >> 2) * 16 + cb * 4 + (r & 3)) * 3 + tp];
+    }
+    __syncthreads();
+  }
+  auto load_off = [&](const int tt, const int tidv) {
+    const int lanev = tidv & 63, wavev = tidv >> 6;
+    const int bb = tt / (tiles_x * tiles_y), tt2 = tt - bb * tiles_x * tiles_y;
+    const int oy0 = (tt2 / tiles_x) * kQY, ox0 = (tt2 % tiles_x) * kQX;
+    const int sdir = lanev >> 5, sit = (lanev >> 3) & 3, spl = lanev & 7;
+    int hp = sit * 32 + wavev * 8 + spl;
+    hp = hp < kQNS ? hp : kQNS - 1;
+    const int hy = hp >> 4, hx = hp & 15;
+    int gy = oy0 + hy - 1, gx = ox0 + hx - 1;
+    gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
+    gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
+    const float* op = (sdir ? a.off[1] : a.off[0]) + (long long)bb * a.off_sb + (gy * a.off_sy + gx * a.off_sx);
+    return make_float2(op[0], op[a.off_sc]);
+  };
+  const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  float2 off_next = make_float2(0.f, 0.f);
+  if (t_begin < t_end) off_next = load_off(t_begin, threadIdx.x);
+  for (int t = t_begin; t < t_end; ++t) {
+    // thread id = scalar wave index * 64 + lane (mbcnt): recomputed per tile, no vector register carried around the loop
+    int tid;                                             // volatile asm: not hoisted out of the tile loop (where it would be spilled)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshl_add_u32 %0, %1, 6, %0" : "=&v"(tid) : "s"(wave_s));
+    // Every phase derives what it needs from its OWN opaque copy of the thread id (a few VALU ops): one shared set of lane
+    // values (pixel coordinates, record addresses, channel offsets) lived across the whole tile and was spilled to scratch -
+    // and a scratch reload between the gather requests waits for all of them (vmcnt retires in order).
+    auto fresh = [&]() { int x = tid; asm volatile("" : "+v"(x)); return x; };
+    const int wave = wave_s;
+    const int b = t / (tiles_x * tiles_y);
+    const int t2 = t - b * tiles_x * tiles_y;
+    const int ty0 = (t2 / tiles_x) * kQY, tx0 = (t2 % tiles_x) * kQX;
+    const int row = ty0 + wave;                          // the wave's row of the v domain (scalar)
+    const int rowc = row > H - 1 ? H - 1 : row;          // clamped = replicate padding of K1 / feat_in
+    // SAC / GEMM role: lane (n, q) = (l & 15, l >> 4) owns pixel (row, tx0 + n - 1), channels q*16 .. q*16+15
+    auto col_of = [&](const int n_) { const int x = tx0 + n_ - 1; return x < 0 ? 0 : (x > W - 1 ? W - 1 : x); };
+    // uniform base + unsigned 32-bit byte offset: the scalar-base addressing form (one offset register per access, no 64-bit pairs)
+    auto ld16 = [](const void* base, const unsigned byte_off) {
+      Pack8<ADT> r;
+      r.a = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + byte_off);
+      r.b = make_uint4(0, 0, 0, 0);
+      return r;
+    };
+    // ---- predictor input of the pixel: cin q*8 .. +7 and 32 + q*8 .. +7 ----
+    uint4 kfr[2];
+    {
+      const int x = fresh(), n = x & 15, q = (x & 63) >> 4;
+      const uint16_t* kb = a.k0 + (long long)b * a.k0_sb + (long long)rowc * a.k0_sy;
+      const unsigned e = (unsigned)(col_of(n) * a.k0_sx + q * 8) * 2u;
+      kfr[0] = ld16(kb, e).a;
+      kfr[1] = ld16(kb, e + 64u).a;
+    }
+    // ---- sampling set-up: lane slot (dir, pass, pixel) = (l >> 5, (l >> 3) & 3, l & 7) of the wave's 8 pixels per pass ----
+    int my_eo[4];
+    float my_w[4];
+    {
+      const int x = fresh(), lane = x & 63;
+      const int sit = (lane >> 3) & 3, spl = lane & 7;
+      int hp = sit * 32 + wave * 8 + spl;
+      hp = hp < kQNS ? hp : kQNS - 1;
+      const int hy = hp >> 4, hx = hp & 15;
+      int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+      gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
+      gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
+      const int psy = a.prev_sy, psx = a.prev_sx;
+      const float fx = (float)gx + off_next.x;
+      const float fy = (float)gy + off_next.y;
+      const float x0f = floorf(fx), y0f = floorf(fy);
+      const float wx1 = fx - x0f, wy1 = fy - y0f;
+      const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+      int wb, hb;                                        // moved and converted here, per tile: hoisted out of the loop the two floats were spilled
+      asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(wb), "=&v"(hb) : "s"(W + 1), "s"(H + 1));
+      const bool sane = (fx > -2.f) && (fx < (float)wb) && (fy > -2.f) && (fy < (float)hb);
+      const int x0 = sane ? (int)x0f : -4, y0 = sane ? (int)y0f : -4;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int xi = x0 + dx, yi = y0 + dy;
+          const bool in = xi >= 0 && xi < W && yi >= 0 && yi < H;
+          const int xc = xi < 0 ? 0 : (xi > W - 1 ? W - 1 : xi), yc = yi < 0 ? 0 : (yi > H - 1 ? H - 1 : yi);
+          my_w[dy * 2 + dx] = in ? (dy ? wy1 : wy0) * (dx ? wx1 : wx0) : 0.f;
+          my_eo[dy * 2 + dx] = yc * psy + xc * psx;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                   // phase fences for the scheduler: hoisting across them cost 30-50 spilled registers
+    Pack8<ADT> fpk[2];                                   // feat_in of the lane's pixel, channels q*16 .. +15 (one direction at a time)
+    auto issue_fin = [&](const int dir) {
+      const int x = fresh(), n = x & 15, q = (x & 63) >> 4;
+      const uint16_t* fb = a.fin[dir] + (long long)b * a.fin_sb + (long long)rowc * a.fin_sy;
+      const unsigned e = (unsigned)(col_of(n) * a.fin_sx + q * 16) * 2u;
+      fpk[0] = ld16(fb, e);
+      fpk[1] = ld16(fb, e + 16u);
+    };
+    Pack8<ADT> tap[ND][NP][4];
+    auto issue_taps = [&](const int dir, const int it0, const int it1) {
+      const int x = fresh(), oct = x & 7, pull = ((x & 63) >> 3) << 2;   // ds_bpermute byte index of lane (l >> 3)
+      const uint16_t* pb = a.prev[dir] + (long long)b * a.prev_sb;
+#pragma unroll
+      for (int it = it0; it < it1; ++it) {
+        const int src = pull + dir * 128 + it * 32;       // + 128 * dir + 32 * pass = the slot's owner
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          tap[dir][it][k] = ld16(pb, (unsigned)(__builtin_amdgcn_ds_bpermute(src, my_eo[k]) + oct * 8) * 2u);
+      }
+    };
+    auto warp_store = [&](const int dir) {
+      const int x = fresh(), oct = x & 7, ps = x >> 3, pull = ((x & 63) >> 3) << 2;
+#pragma unroll
+      for (int it = 0; it < NP; ++it) {
+        const int hp = it * 32 + ps;
+        const int src = pull + dir * 128 + it * 32;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float tw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tw[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(my_w[k])));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float v[8];
+          unpack8<ADT>(tap[dir][it][k], v);
+          const float w = tw[k];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) acc[c] = fmaf(v[c], w, acc[c]);
+        }
+        float* rec = s_s + hp * kJC;
+        *reinterpret_cast<float4*>(rec + (((2 * oct) ^ (hp & 15)) << 2)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(rec + (((2 * oct + 1) ^ (hp & 15)) << 2)) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    issue_taps(0, 0, NP);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- predictor GEMM of the wave's pixel row: K1p[t*4 + cb] = kernels of channels q*16 + cb*4 .. +3, tap t (16-bit, what
+    // the stand-alone F[1] launch would have stored) ----
+    uint2 K1p[12];
+    {
+      const int x = fresh(), n = x & 15, q = (x & 63) >> 4;
+#pragma unroll
+      for (int mt = 0; mt < 12; ++mt) {
+        const int R = mt * 16 + n;
+        const uint4 w0 = *reinterpret_cast<const uint4*>(w_s + R * kJC + ((q ^ (R & 7)) << 3));
+        const uint4 w1 = *reinterpret_cast<const uint4*>(w_s + R * kJC + (((q + 4) ^ (R & 7)) << 3));
+        f32x4v_t acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mfma16x<BF>(w0, kfr[0], acc);
+        acc = mfma16x<BF>(w1, kfr[1], acc);
+        const float4 b4 = *reinterpret_cast<const float4*>(kb_s + mt * 16 + q * 4);
+        K1p[mt] = cvt4<BF>(make_float4(acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w));
+        if (mt & 1) __builtin_amdgcn_sched_barrier(0);   // two M-tiles of operands in flight, not all twelve (96 registers)
+      }
+    }
+    auto sac = [&](const int dir) {
+      float4 vr[4];
+      {
+        const int x = fresh(), n = x & 15, q = (x & 63) >> 4;
+        // ---- vertical: v[row][n] = sum_t s[row + t][n] * K1[row][n][t] ----
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+          float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int tt = 0; tt < 3; ++tt) {
+            const int P = (wave + tt) * kQVX + n;
+            const float4 sv = *reinterpret_cast<const float4*>(s_s + P * kJC + (((q * 4 + cb) ^ (P & 15)) << 2));
+            float k[4];
+            cvt16x4_to_f32<BF>(K1p[tt * 4 + cb], k);
+            acc[0] = fmaf(sv.x, k[0], acc[0]); acc[1] = fmaf(sv.y, k[1], acc[1]);
+            acc[2] = fmaf(sv.z, k[2], acc[2]); acc[3] = fmaf(sv.w, k[3], acc[3]);
+          }
+          vr[cb] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      issue_fin(dir);                                    // the residual is consumed after the next two barriers
+      __syncthreads();                                   // every wave has read its three rows of s: v may overwrite rows 0..3
+      {
+        const int x = fresh(), n = x & 15, q = (x & 63) >> 4;
+        const int P = wave * kQVX + n;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) *reinterpret_cast<float4*>(v_s + P * kJC + (((q * 4 + cb) ^ (P & 15)) << 2)) = vr[cb];
+      }
+      __syncthreads();
+      // ---- horizontal (kernel1 again) + residual + LeakyReLU ----
+      const int x = fresh(), n = x & 15, q = (x & 63) >> 4;
+      const int gx = tx0 + n - 1;
+      if (n >= 1 && n <= kQX && row < H && gx < W) {
+        uint16_t* const db = a.dst[dir] + (long long)b * a.dst_sb + (long long)row * a.dst_sy;
+        const int e = gx * a.dst_sx + q * 16;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {                  // 8 channels at a time
+          float f[8], o[8];
+          unpack8<ADT>(fpk[hf], f);
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2) {
+            const int cb = hf * 2 + c2;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) {
+              const int P = wave * kQVX + n + tt - 1;
+              const float4 vv = *reinterpret_cast<const float4*>(v_s + P * kJC + (((q * 4 + cb) ^ (P & 15)) << 2));
+              float k[4];
+              cvt16x4_to_f32<BF>(K1p[tt * 4 + cb], k);
+              acc[0] = fmaf(vv.x, k[0], acc[0]); acc[1] = fmaf(vv.y, k[1], acc[1]);
+              acc[2] = fmaf(vv.z, k[2], acc[2]); acc[3] = fmaf(vv.w, k[3], acc[3]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float r = acc[i] + f[c2 * 4 + i];
+              o[c2 * 4 + i] = r >= 0.f ? r : r * slope;
+            }
+          }
+          st_p8<ADT>(reinterpret_cast<float*>(db), e + hf * 8, o);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    warp_store(0);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_taps(1, 0, FCVSR_IAC2_EARLY);                  // in flight during direction 0's LDS phases
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    sac(0);
+    issue_taps(1, FCVSR_IAC2_EARLY, NP);
+    // the next tile's offsets head its longest dependency chain (offsets -> addresses -> gather): requested here, where few
+    // registers are live (before direction 0's phases the two values were spilled, and the spill waited for every gather)
+    if (t + 1 < t_end) off_next = load_off(t + 1, fresh());
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                     // v of direction 0 has been read: s may be rewritten
+    warp_store(1);
+    __syncthreads();
+    sac(1);
+    __syncthreads();                                     // next tile's warp_store(0) rewrites s / v
+  }
+}
+
 }  // namespace fcvsr
 
 using namespace fcvsr;
@@ -797,6 +1107,33 @@ extern "C" int fcvsr_iac_step2_fused(const fcvsr_view* prev, const fcvsr_view* o
   a.k1 = to_view(*k0); a.k0 = to_view(*k0); a.wk = (const uint16_t*)wk; a.kbias = kbias;
   a.slope = slope; a.B = B; a.H = H; a.W = W; a.tiles_x = tx; a.tiles_y = ty;
   hipStream_t st = (hipStream_t)stream;
+  static const int form = getenv("FCVSR_IAC_FORM") ? atoi(getenv("FCVSR_IAC_FORM")) : 2;   // 1 = iac_step64_kernel (kernels through LDS)
+  bool same = adt != FCVSR_F32 && adt == k0->dtype && (long long)H * k0->sy < (1ll << 31);
+  {
+    const fcvsr_view* sets[4] = {prev, off, feat_in, dst};
+    for (const fcvsr_view* v : sets)
+      same = same && v[0].sb == v[1].sb && v[0].sy == v[1].sy && v[0].sx == v[1].sx && v[0].sc == v[1].sc && (long long)H * v[0].sy < (1ll << 31);
+  }
+  if (form == 2 && same) {   // kernels in registers, three workgroups per CU (iac_fused2_kernel)
+    Iac2Args q;
+    for (int d = 0; d < 2; ++d) {
+      q.prev[d] = (const uint16_t*)prev[d].ptr; q.off[d] = (const float*)off[d].ptr;
+      q.fin[d] = (const uint16_t*)feat_in[d].ptr; q.dst[d] = (uint16_t*)dst[d].ptr;
+    }
+    q.k0 = (const uint16_t*)k0->ptr; q.wk = (const uint16_t*)wk; q.kbias = kbias;
+    q.prev_sb = prev[0].sb; q.off_sb = off[0].sb; q.fin_sb = feat_in[0].sb; q.dst_sb = dst[0].sb; q.k0_sb = k0->sb;
+    q.prev_sy = (int)prev[0].sy; q.prev_sx = (int)prev[0].sx; q.off_sy = (int)off[0].sy; q.off_sx = (int)off[0].sx; q.off_sc = (int)off[0].sc;
+    q.fin_sy = (int)feat_in[0].sy; q.fin_sx = (int)feat_in[0].sx; q.dst_sy = (int)dst[0].sy; q.dst_sx = (int)dst[0].sx;
+    q.k0_sy = (int)k0->sy; q.k0_sx = (int)k0->sx;
+    q.slope = slope; q.H = H; q.W = W; q.tiles_x = cdiv(W, kQX); q.tiles_y = cdiv(H, kQY); q.ntiles = B * q.tiles_x * q.tiles_y;
+    int nwg = iac_persistent_wgs() / 2 * FCVSR_IAC2_WGS;
+    nwg = nwg < 8 ? 8 : nwg / 8 * 8;
+    if (nwg > q.ntiles) nwg = q.ntiles;
+    if (adt == FCVSR_BF16) hipLaunchKernelGGL((iac_fused2_kernel<FCVSR_BF16, FCVSR_BF16>), dim3(nwg), dim3(256), 0, st, q);
+    else hipLaunchKernelGGL((iac_fused2_kernel<FCVSR_F16, FCVSR_F16>), dim3(nwg), dim3(256), 0, st, q);
+    FCVSR_LAUNCH_CHECK();
+    return 0;
+  }
   if (k0->dtype == FCVSR_BF16) launch_iac64<FCVSR_BF16, 2, true>(adt, grid, st, a);
   else launch_iac64<FCVSR_F16, 2, true>(adt, grid, st, a);
   FCVSR_LAUNCH_CHECK();

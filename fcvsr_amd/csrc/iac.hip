@@ -683,15 +683,16 @@ struct Iac2Args {        // compact: both directions share every stride (host-ch
 #ifndef FCVSR_IAC2_EARLY
 #define FCVSR_IAC2_EARLY 2
 #endif
-template <int KDT, int ADT>
-__global__ __launch_bounds__(256, FCVSR_IAC2_WGS) void iac_fused2_kernel(Iac2Args a) {
+// NG = 2: a workgroup of 8 waves walks TWO tiles at a time (wave group g = waves 4g .. 4g+3, its own s / v tile) over one copy
+// of the predictor weights: 74.6 KB per 8 waves, two workgroups = 16 waves per CU (the 4-wave form: 49.9 KB, 12 waves per CU).
+template <int KDT, int ADT, int NG>
+__global__ __launch_bounds__(256 * NG, NG == 2 ? 2 : FCVSR_IAC2_WGS) void iac_fused2_kernel(Iac2Args a) {
   static_assert(ADT != FCVSR_F32 && KDT != FCVSR_F32, "16-bit form");
   constexpr bool BF = KDT == FCVSR_BF16;
   constexpr int ND = 2, NP = kQNS / 32;                  // 3 gather passes of 32 pixel slots
-  __shared__ __align__(16) float s_s[kQNS * kJC];        // 24,576 B; v = records 0..63
+  __shared__ __align__(16) float s_all[NG * kQNS * kJC]; // 24,576 B per wave group; v = records 0..63
   __shared__ __align__(16) uint16_t w_s[3 * kJC * kJC];  // 24,576 B, 16-byte segments XOR (row & 7)
   __shared__ __align__(16) float kb_s[3 * kJC];
-  float* const v_s = s_s;
   const float slope = a.slope;
   const int H = a.H, W = a.W, tiles_x = a.tiles_x, tiles_y = a.tiles_y;
   int t_begin, t_end;
@@ -704,8 +705,8 @@ __global__ __launch_bounds__(256, FCVSR_IAC2_WGS) void iac_fused2_kernel(Iac2Arg
   {                                                      // predictor weights (rows permuted) and bias: once per workgroup
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 3 * kJC * kJC / 8 / 256; ++i) {
-      const int idx = tid + 256 * i, R = idx >> 3, seg = idx & 7;
+    for (int i = 0; i < 3 * kJC * kJC / 8 / (256 * NG); ++i) {
+      const int idx = tid + 256 * NG * i, R = idx >> 3, seg = idx & 7;
       const int mt = R >> 4, r = R & 15, tp = mt >> 2, cb = mt & 3;
       const int orig = ((r >> 2) * 16 + cb * 4 + (r & 3)) * 3 + tp;
       *reinterpret_cast<uint4*>(w_s + R * kJC + ((seg ^ (R & 7)) << 3)) = *reinterpret_cast<const uint4*>(a.wk + orig * kJC + seg * 8);
@@ -730,10 +731,20 @@ __global__ __launch_bounds__(256, FCVSR_IAC2_WGS) void iac_fused2_kernel(Iac2Arg
     const float* op = (sdir ? a.off[1] : a.off[0]) + (long long)bb * a.off_sb + (gy * a.off_sy + gx * a.off_sx);
     return make_float2(op[0], op[a.off_sc]);
   };
-  const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wave_a = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wave_s = wave_a & 3, grp = wave_a >> 2;      // row of the tile, wave group (scalars)
+  float* const s_s = s_all + grp * (kQNS * kJC);
+  float* const v_s = s_s;
   float2 off_next = make_float2(0.f, 0.f);
-  if (t_begin < t_end) off_next = load_off(t_begin, threadIdx.x);
-  for (int t = t_begin; t < t_end; ++t) {
+  {
+    int t0 = t_begin + grp;
+    t0 = t0 < t_end ? t0 : t_end - 1;
+    if (t_begin < t_end) off_next = load_off(t0, (int)threadIdx.x & 255);
+  }
+  for (int tb = t_begin; tb < t_end; tb += NG) {
+    // a group past the end of the run repeats the last tile with its stores switched off: every wave meets every barrier
+    const bool live = tb + grp < t_end;
+    const int t = live ? tb + grp : t_end - 1;
     // thread id = scalar wave index * 64 + lane (mbcnt): recomputed per tile, no vector register carried around the loop
     int tid;                                             // volatile asm: not hoisted out of the tile loop (where it would be spilled)
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshl_add_u32 %0, %1, 6, %0" : "=&v"(tid) : "s"(wave_s));
@@ -848,7 +859,12 @@ __global__ __launch_bounds__(256, FCVSR_IAC2_WGS) void iac_fused2_kernel(Iac2Arg
     __builtin_amdgcn_sched_barrier(0);
     // ---- predictor GEMM of the wave's pixel row: K1p[t*4 + cb] = kernels of channels q*16 + cb*4 .. +3, tap t (16-bit, what
     // the stand-alone F[1] launch would have stored) ----
-    uint2 K1p[12];
+#ifndef FCVSR_IAC2_KF32
+#define FCVSR_IAC2_KF32 1
+#endif
+    constexpr bool KF = FCVSR_IAC2_KF32 != 0 && NG == 1 && BF;   // kernels kept as (rounded) f32: 24 more registers, 144 fewer conversions per tile (bf16: two VALU ops per pair)
+    uint2 K1p[KF ? 1 : 12];
+    float K1f[KF ? 12 : 1][4];
     {
       const int x = fresh(), n = x & 15, q = (x & 63) >> 4;
 #pragma unroll
@@ -860,7 +876,9 @@ __global__ __launch_bounds__(256, FCVSR_IAC2_WGS) void iac_fused2_kernel(Iac2Arg
         acc = mfma16x<BF>(w0, kfr[0], acc);
         acc = mfma16x<BF>(w1, kfr[1], acc);
         const float4 b4 = *reinterpret_cast<const float4*>(kb_s + mt * 16 + q * 4);
-        K1p[mt] = cvt4<BF>(make_float4(acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w));
+        const uint2 pk = cvt4<BF>(make_float4(acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w));
+        if (KF) cvt16x4_to_f32<BF>(pk, K1f[mt]);
+        else K1p[mt] = pk;
         if (mt & 1) __builtin_amdgcn_sched_barrier(0);   // two M-tiles of operands in flight, not all twelve (96 registers)
       }
     }
@@ -877,7 +895,8 @@ __global__ __launch_bounds__(256, FCVSR_IAC2_WGS) void iac_fused2_kernel(Iac2Arg
             const int P = (wave + tt) * kQVX + n;
             const float4 sv = *reinterpret_cast<const float4*>(s_s + P * kJC + (((q * 4 + cb) ^ (P & 15)) << 2));
             float k[4];
-            cvt16x4_to_f32<BF>(K1p[tt * 4 + cb], k);
+            if (KF) { k[0] = K1f[tt * 4 + cb][0]; k[1] = K1f[tt * 4 + cb][1]; k[2] = K1f[tt * 4 + cb][2]; k[3] = K1f[tt * 4 + cb][3]; }
+            else cvt16x4_to_f32<BF>(K1p[tt * 4 + cb], k);
             acc[0] = fmaf(sv.x, k[0], acc[0]); acc[1] = fmaf(sv.y, k[1], acc[1]);
             acc[2] = fmaf(sv.z, k[2], acc[2]); acc[3] = fmaf(sv.w, k[3], acc[3]);
           }
@@ -897,7 +916,7 @@ __global__ __launch_bounds__(256, FCVSR_IAC2_WGS) void iac_fused2_kernel(Iac2Arg
       // ---- horizontal (kernel1 again) + residual + LeakyReLU ----
       const int x = fresh(), n = x & 15, q = (x & 63) >> 4;
       const int gx = tx0 + n - 1;
-      if (n >= 1 && n <= kQX && row < H && gx < W) {
+      if (n >= 1 && n <= kQX && row < H && gx < W && live) {
         uint16_t* const db = a.dst[dir] + (long long)b * a.dst_sb + (long long)row * a.dst_sy;
         const int e = gx * a.dst_sx + q * 16;
 #pragma unroll
@@ -913,7 +932,8 @@ __global__ __launch_bounds__(256, FCVSR_IAC2_WGS) void iac_fused2_kernel(Iac2Arg
               const int P = wave * kQVX + n + tt - 1;
               const float4 vv = *reinterpret_cast<const float4*>(v_s + P * kJC + (((q * 4 + cb) ^ (P & 15)) << 2));
               float k[4];
-              cvt16x4_to_f32<BF>(K1p[tt * 4 + cb], k);
+              if (KF) { k[0] = K1f[tt * 4 + cb][0]; k[1] = K1f[tt * 4 + cb][1]; k[2] = K1f[tt * 4 + cb][2]; k[3] = K1f[tt * 4 + cb][3]; }
+              else cvt16x4_to_f32<BF>(K1p[tt * 4 + cb], k);
               acc[0] = fmaf(vv.x, k[0], acc[0]); acc[1] = fmaf(vv.y, k[1], acc[1]);
               acc[2] = fmaf(vv.z, k[2], acc[2]); acc[3] = fmaf(vv.w, k[3], acc[3]);
             }
@@ -938,7 +958,11 @@ __global__ __launch_bounds__(256, FCVSR_IAC2_WGS) void iac_fused2_kernel(Iac2Arg
     issue_taps(1, FCVSR_IAC2_EARLY, NP);
     // the next tile's offsets head its longest dependency chain (offsets -> addresses -> gather): requested here, where few
     // registers are live (before direction 0's phases the two values were spilled, and the spill waited for every gather)
-    if (t + 1 < t_end) off_next = load_off(t + 1, fresh());
+    if (tb + NG < t_end) {
+      int tn = tb + NG + grp;
+      tn = tn < t_end ? tn : t_end - 1;
+      off_next = load_off(tn, fresh());
+    }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                                     // v of direction 0 has been read: s may be rewritten
     warp_store(1);
@@ -1126,11 +1150,20 @@ extern "C" int fcvsr_iac_step2_fused(const fcvsr_view* prev, const fcvsr_view* o
     q.fin_sy = (int)feat_in[0].sy; q.fin_sx = (int)feat_in[0].sx; q.dst_sy = (int)dst[0].sy; q.dst_sx = (int)dst[0].sx;
     q.k0_sy = (int)k0->sy; q.k0_sx = (int)k0->sx;
     q.slope = slope; q.H = H; q.W = W; q.tiles_x = cdiv(W, kQX); q.tiles_y = cdiv(H, kQY); q.ntiles = B * q.tiles_x * q.tiles_y;
+    static const int ng = getenv("FCVSR_IAC_NG") ? atoi(getenv("FCVSR_IAC_NG")) : 1;   // 2: measured equal (252 vs 248 us): not the default
+    if (ng == 2 && adt == FCVSR_BF16) {                  // 8 waves per workgroup, two per CU (the f16 form needs 136 registers: 4-wave form)
+      int nwg = iac_persistent_wgs();
+      nwg = nwg < 8 ? 8 : nwg / 8 * 8;
+      if (nwg > (q.ntiles + 1) / 2) nwg = (q.ntiles + 1) / 2;
+      hipLaunchKernelGGL((iac_fused2_kernel<FCVSR_BF16, FCVSR_BF16, 2>), dim3(nwg), dim3(512), 0, st, q);
+      FCVSR_LAUNCH_CHECK();
+      return 0;
+    }
     int nwg = iac_persistent_wgs() / 2 * FCVSR_IAC2_WGS;
     nwg = nwg < 8 ? 8 : nwg / 8 * 8;
     if (nwg > q.ntiles) nwg = q.ntiles;
-    if (adt == FCVSR_BF16) hipLaunchKernelGGL((iac_fused2_kernel<FCVSR_BF16, FCVSR_BF16>), dim3(nwg), dim3(256), 0, st, q);
-    else hipLaunchKernelGGL((iac_fused2_kernel<FCVSR_F16, FCVSR_F16>), dim3(nwg), dim3(256), 0, st, q);
+    if (adt == FCVSR_BF16) hipLaunchKernelGGL((iac_fused2_kernel<FCVSR_BF16, FCVSR_BF16, 1>), dim3(nwg), dim3(256), 0, st, q);
+    else hipLaunchKernelGGL((iac_fused2_kernel<FCVSR_F16, FCVSR_F16, 1>), dim3(nwg), dim3(256), 0, st, q);
     FCVSR_LAUNCH_CHECK();
     return 0;
   }

@@ -354,13 +354,18 @@ def test_iac_step2_equals_two_single_steps(adt):
     assert torch.equal(outs[0], ref[0]) and torch.equal(outs[1], ref[1])
 
 
-@pytest.mark.parametrize("adt,kdt", [("bf16", "bf16"), ("f32", "bf16"), ("f16", "f16")])
-def test_iac_step2_fused_predictor_equals_unfused(adt, kdt):
+@pytest.mark.parametrize("adt,kdt,shape", [("bf16", "bf16", (2, 18, 37)), ("f32", "bf16", (2, 18, 37)), ("f16", "f16", (2, 18, 37)),
+                                           ("bf16", "bf16", (1, 4, 14)), ("bf16", "bf16", (3, 5, 3)), ("bf16", "bf16", (1, 9, 29)),
+                                           ("f16", "f16", (2, 7, 15)), ("bf16", "bf16", (1, 33, 71))])
+def test_iac_step2_fused_predictor_equals_unfused(adt, kdt, shape):
     """F[1] folded into the IAC kernel: same result as the stand-alone 1x1 MFMA convolution (16-bit K) followed by the
-    two-direction IAC launch - the fold changes where the kernels live (LDS instead of HBM), not their values."""
+    two-direction IAC launch - the fold changes where the kernels live (registers / LDS instead of HBM), not their values.
+    16-bit activations take iac_fused2_kernel (kernels in MFMA accumulator layout, 4 x 14 tiles: the shapes cover one exact
+    tile, partial tiles in both directions and images smaller than a tile), f32 activations iac_step64_kernel."""
     from fcvsr_amd import hip
     L = hip.lib()
-    B, Cc, H, W = 2, 64, 18, 37
+    Cc = 64
+    B, H, W = shape
     tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[adt]
     mdt = {"bf16": torch.bfloat16, "f16": torch.float16}[kdt]
     mcode = hip.BF16 if kdt == "bf16" else hip.F16

@@ -296,6 +296,151 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(WgradArgs a, int til
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Second form (round 3): the same products without the transposing stores.  The workgroup stages its tiles PIXEL-major, as they
+// lie in memory - 8 floats -> one 16-byte ds_write_b128 of bf16 per lane (the first form issues four 2-byte ds_write_b16 per
+// 4 channels, three times over for the pre-shifted x images: ~12 us of staging per 4 x 32 tile) - and lets the LDS do the
+// transpose on the way out: ds_read_b64_tr_b16 hands lane i of a 16-lane group channel i of 4 consecutive pixel records, which is
+// exactly the "8 consecutive k of one row" the MFMA operands want when k runs over pixels.  A tap's shift is a whole number of
+// 128-byte pixel records, so ONE x image serves all nine taps, and a fragment of x row yy is read once for the (up to three)
+// taps that use it: 88 transposed 8-byte reads per wave and tile feed its 72 MFMAs (first form: 80 ds_read_b128).
+// Records are 8 chunks of 16 bytes; chunk c of pixel record P sits in slot c ^ (4 * ((P >> 1) & 1)): the 4 rows x 2 blocks of a
+// 32-lane half then cover all 64 banks once, for any start pixel.  Same MFMA instruction, same k order per tap: results are
+// bit-identical to the first form.
+typedef __attribute__((ext_vector_type(4))) short wg_s4_t;
+
+__device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {
+  const wg_s4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s4_t*)(p));
+  return __builtin_bit_cast(uint2, v);
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WgradArgs a, int tiles_x, int tiles_y, int tiles_per_slab) {
+  constexpr int PAD = KS / 2, HY = kGTY + 2 * PAD, HXW = kGTX + 2 * PAD;
+  constexpr int NGY = kGTY * kGTX, NX = HY * HXW;
+  __shared__ __align__(16) unsigned char gy_s[NGY * 128];
+  __shared__ __align__(16) unsigned char x_s[NX * 128];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mf = wave >> 1, nf = wave & 1;               // this wave's (cout, cin) fragment pair
+  const int nci = a.cin / 64;
+  const int co0 = (blockIdx.y / nci) * 64, ci0 = (blockIdx.y % nci) * 64;
+  const int slab = blockIdx.x;
+  const int total_tiles = a.B * tiles_x * tiles_y;
+  const int t_begin = slab * tiles_per_slab;
+  int t_end = t_begin + tiles_per_slab;
+  if (t_end > total_tiles) t_end = total_tiles;
+  // transposed-read addresses: 16-lane group g4 = (k half kg, channel half mh); lane 4q + p supplies row q, channels 4p .. 4p+3
+  const int g4 = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3, kg = g4 >> 1, mh = g4 & 1;
+  const int cA = mf * 4 + 2 * mh + (p4 >> 1), cB = nf * 4 + 2 * mh + (p4 >> 1);
+  // gy: k-steps start at multiples of 16 pixels, so the slot XOR depends on q alone
+  const unsigned addrA = (unsigned)((8 * kg + q) * 128 + 16 * (cA ^ (((q >> 1) & 1) << 2)) + 8 * (p4 & 1));
+  unsigned addrB[4];                                      // x: the start pixel's residue mod 4 (tap shift, row pitch 34) picks the variant
+#pragma unroll
+  for (int b4 = 0; b4 < 4; ++b4)
+    addrB[b4] = (unsigned)((8 * kg + q) * 128 + 16 * (cB ^ ((((b4 + q) >> 1) & 1) << 2)) + 8 * (p4 & 1));
+
+  f32x16_t acc[KS * KS];
+#pragma unroll
+  for (int t = 0; t < KS * KS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  const int c8 = tid & 7, ps = tid >> 3;                  // staging role: 8-channel chunk, pixel slot (32 per pass)
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int b = tile / (tiles_x * tiles_y);
+    const int t2 = tile - b * tiles_x * tiles_y;
+    const int ty0 = (t2 / tiles_x) * kGTY, tx0 = (t2 % tiles_x) * kGTX;
+    // ---- staging: gy (4 passes of 32 pixels) and x (7 passes for KS = 3, 4 for KS = 1), two float4 per lane and pass; x in two
+    // batches so that at most 7 passes (56 registers) are in flight next to the 144 accumulator registers -----------------------
+    constexpr int PGY = NGY / 32, PX = (NX + 31) / 32, PXA = PX > 4 ? 3 : PX;
+    auto load_x = [&](const int i, float4* v) {
+      const int P = i * 32 + ps;
+      const int hy = P / HXW, hx = P - hy * HXW;
+      const int iy = ty0 + hy - PAD, ix = tx0 + hx - PAD;
+      v[0] = v[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (P < NX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+        const float* src = a.x.p + (long long)b * a.x.sb + (long long)iy * a.x.sy + (long long)ix * a.x.sx + ci0 + c8 * 8;
+        v[0] = *reinterpret_cast<const float4*>(src);
+        v[1] = *reinterpret_cast<const float4*>(src + 4);
+      }
+    };
+    auto store_rec = [&](unsigned char* img, const int P, const float4* v) {
+      const uint2 lo = cvt4<true>(v[0]), hi = cvt4<true>(v[1]);
+      *reinterpret_cast<uint4*>(img + P * 128 + 16 * (c8 ^ (((P >> 1) & 1) << 2))) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    };
+    {
+      float4 gv[PGY][2], xv[PXA][2];
+#pragma unroll
+      for (int i = 0; i < PGY; ++i) {
+        const int P = i * 32 + ps, y = P >> 5, x = P & 31;
+        const int gyy = ty0 + y, gxx = tx0 + x;
+        gv[i][0] = gv[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gyy < a.Ho && gxx < a.Wo) {
+          const float* src = a.gy.p + (long long)b * a.gy.sb + (long long)gyy * a.gy.sy + (long long)gxx * a.gy.sx + co0 + c8 * 8;
+          gv[i][0] = *reinterpret_cast<const float4*>(src);
+          gv[i][1] = *reinterpret_cast<const float4*>(src + 4);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < PXA; ++i) load_x(i, xv[i]);
+      __syncthreads();                                   // the previous tile's images are no longer read
+#pragma unroll
+      for (int i = 0; i < PGY; ++i) store_rec(gy_s, i * 32 + ps, gv[i]);
+#pragma unroll
+      for (int i = 0; i < PXA; ++i) store_rec(x_s, i * 32 + ps, xv[i]);
+    }
+    if (PX > PXA) {
+      float4 xv[PX - PXA > 0 ? PX - PXA : 1][2];
+#pragma unroll
+      for (int i = PXA; i < PX; ++i) load_x(i, xv[i - PXA]);
+#pragma unroll
+      for (int i = PXA; i < PX; ++i)
+        if (i * 32 + ps < NX) store_rec(x_s, i * 32 + ps, xv[i - PXA]);
+    }
+    __syncthreads();
+    // ---- A fragments of the tile's 8 k-steps (row y, half s), kept for the whole tile --------------------------------------
+    uint4 af[kGTY][2];
+#pragma unroll
+    for (int y = 0; y < kGTY; ++y)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const unsigned char* pa = gy_s + addrA + (y * kGTX + s2 * 16) * 128;
+        const uint2 lo = lds_tr16(pa), hi = lds_tr16(pa + 4 * 128);
+        af[y][s2] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+    // ---- x row yy, half s, shift kx: one fragment for the taps (ky = yy - y, kx) with 0 <= y < 4 ---------------------------------
+#pragma unroll
+    for (int yy = 0; yy < HY; ++yy)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const int P0 = yy * HXW + s2 * 16 + kx;          // start pixel of the k-step in the x image (compile-time)
+          const unsigned char* pb = x_s + addrB[P0 & 3] + P0 * 128;
+          const uint2 lo = lds_tr16(pb), hi = lds_tr16(pb + 4 * 128);
+          const uint4 bf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+          for (int ky = 0; ky < KS; ++ky) {
+            const int y = yy - ky;
+            if (y >= 0 && y < kGTY) acc[ky * KS + kx] = mfma<true>(af[y][s2], bf, acc[ky * KS + kx]);
+          }
+        }
+  }
+  // ---- partial[slab][tap][ci][co]: lane (r = ci, h) holds couts (i&3) + 8 (i>>2) + 4h of its fragment ---------------------------
+  const int r = lane & 31, h = lane >> 5;
+  float* pp = a.partial + ((long long)slab * (KS * KS)) * a.cin * a.cout;
+#pragma unroll
+  for (int t = 0; t < KS * KS; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = co0 + mf * 32 + 8 * g + 4 * h, ci = ci0 + nf * 32 + r;
+      *reinterpret_cast<float4*>(pp + ((long long)t * a.cin + ci) * a.cout + co) =
+          make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+    }
+}
+
 }  // namespace fcvsr
 
 static int wgrad_mfma_slabs(int B, int Ho, int Wo, int cin, int cout) {
@@ -313,6 +458,29 @@ static int wgrad_mfma_slabs(int B, int Ho, int Wo, int cin, int cout) {
   if (n > tiles) n = tiles;
   if (n < 1) n = 1;
   return n;
+}
+
+// FCVSR_WGRAD_FORM: 2 (default) = wgrad_tr_kernel (pixel-major images, transposing LDS reads), 1 = wgrad_mfma_kernel (transposing stores)
+static int launch_wgrad_mfma(const WgradArgs& a, dim3 grid, int kh, int tiles_x, int tiles_y, int per_slab, hipStream_t st) {
+  static const int form = getenv("FCVSR_WGRAD_FORM") ? atoi(getenv("FCVSR_WGRAD_FORM")) : 2;
+  if (form == 2) {
+    if (kh == 3) hipLaunchKernelGGL(wgrad_tr_kernel<3>, grid, dim3(256), 0, st, a, tiles_x, tiles_y, per_slab);
+    else hipLaunchKernelGGL(wgrad_tr_kernel<1>, grid, dim3(256), 0, st, a, tiles_x, tiles_y, per_slab);
+    return 0;
+  }
+  if (kh == 3) {
+    const size_t ldsb = 64 * kGyPitch + 3 * 64 * ((kGTY + 2) * kGTX * 2 + 16);
+    static DevOnce attr3;
+    hipError_t e = once_per_device(attr3, [&] {
+      return hipFuncSetAttribute((const void*)wgrad_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    });
+    if (e != hipSuccess) { set_error("fcvsr_conv2d_wgrad_mfma: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(wgrad_mfma_kernel<3>, grid, dim3(256), ldsb, st, a, tiles_x, tiles_y, per_slab);
+  } else {
+    const size_t ldsb = 64 * kGyPitch + 64 * (kGTY * kGTX * 2 + 16);
+    hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), ldsb, st, a, tiles_x, tiles_y, per_slab);
+  }
+  return 0;
 }
 
 extern "C" long long fcvsr_conv2d_wgrad_mfma_scratch_elems(int B, int Ho, int Wo, int cin, int cout, int kh, int kw) {
@@ -346,18 +514,7 @@ extern "C" int fcvsr_conv2d_wgrad_mfma(const fcvsr_view* x, const fcvsr_view* gy
   const int per_slab = (total + a.n_slabs - 1) / a.n_slabs;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(a.n_slabs, (a.cin / 64) * (a.cout / 64));
-  if (kh == 3) {
-    const size_t ldsb = 64 * kGyPitch + 3 * 64 * ((kGTY + 2) * kGTX * 2 + 16);
-    static DevOnce attr3;
-    hipError_t e = once_per_device(attr3, [&] {
-      return hipFuncSetAttribute((const void*)wgrad_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    });
-    if (e != hipSuccess) { set_error("fcvsr_conv2d_wgrad_mfma: %s", hipGetErrorString(e)); return (int)e; }
-    hipLaunchKernelGGL(wgrad_mfma_kernel<3>, grid, dim3(256), ldsb, st, a, tiles_x, tiles_y, per_slab);
-  } else {
-    const size_t ldsb = 64 * kGyPitch + 64 * (kGTY * kGTX * 2 + 16);
-    hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), ldsb, st, a, tiles_x, tiles_y, per_slab);
-  }
+  { const int e = launch_wgrad_mfma(a, grid, kh, tiles_x, tiles_y, per_slab, st); if (e) return e; }
   FCVSR_LAUNCH_CHECK();
   const long long n = (long long)a.cout * a.cin * kh * kw;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
@@ -403,18 +560,7 @@ extern "C" int fcvsr_conv2d_wgrad_mfma_groups(const fcvsr_view* xs, const fcvsr_
     const int total = B[g] * tiles_x * tiles_y;
     const int per_slab = (total + a.n_slabs - 1) / a.n_slabs;
     const dim3 grid(a.n_slabs, (cin / 64) * (cout / 64));
-    if (kh == 3) {
-      const size_t ldsb = 64 * kGyPitch + 3 * 64 * ((kGTY + 2) * kGTX * 2 + 16);
-      static DevOnce attr3;
-      hipError_t e = once_per_device(attr3, [&] {
-        return hipFuncSetAttribute((const void*)wgrad_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-      });
-      if (e != hipSuccess) { set_error("fcvsr_conv2d_wgrad_mfma_groups: %s", hipGetErrorString(e)); return (int)e; }
-      hipLaunchKernelGGL(wgrad_mfma_kernel<3>, grid, dim3(256), ldsb, st, a, tiles_x, tiles_y, per_slab);
-    } else {
-      const size_t ldsb = 64 * kGyPitch + 64 * (kGTY * kGTX * 2 + 16);
-      hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), ldsb, st, a, tiles_x, tiles_y, per_slab);
-    }
+    { const int e = launch_wgrad_mfma(a, grid, kh, tiles_x, tiles_y, per_slab, st); if (e) return e; }
     FCVSR_LAUNCH_CHECK();
     slab0 += a.n_slabs;
   }

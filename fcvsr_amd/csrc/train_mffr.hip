@@ -2,7 +2,7 @@
 // bands i >= 1 of the reversed band list):
 //     t  = f - Sf + 0.2 So;   e1 = (0.2 a t + b) f;   e2 = (0.2 a So + b) f;   o = e1 * CA(e1) + e2 * CA(e2);   Sf' = Sf + f;   So' = So + o
 //     CA(e)[b][c] = sigmoid( W2 relu( W1 mean_HW(e) ) )       (CALayer :1812-1828, the SAME weights for both applications)
-// forward in three launches, backward in four + the final row sums, on dense (B, HW, C) f32 tensors (C = 32 or 64, C / 16 hidden
+// forward in three launches, backward in four (three passes + one launch for the four final row sums), on dense (B, HW, C) f32 tensors (C = 32 or 64, C / 16 hidden
 // units).  Under autograd a band was ~30 forward and ~55 backward torch kernels (broadcast multiplies, means, tiny matmuls).
 // Backward (gSf', gSo' given; g_o = gSo'):
 //   gg_k[b][c] = sum_p g_o e_k;  through the gate: gu = gg g (1 - g), gz = (W2^T gu) [z > 0], gm = W1^T gz, dW2 += gu (x) z, dW1 += gz (x) m;
@@ -210,13 +210,47 @@ __global__ __launch_bounds__(256) void dvb_bwd2_kernel(const float* __restrict__
   }
 }
 
-// out[i] (+)= sum_j in[j * stride + i], rows in order
-__global__ __launch_bounds__(256) void dvb_rowsum_kernel(const float* __restrict__ in, int rows, long long stride, int n, float* __restrict__ out, int accumulate) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int j = 0; j < rows; ++j) s += in[(long long)j * stride + i];
-  out[i] = accumulate ? out[i] + s : s;
+// The four final row sums in one launch, fixed order: block 0 -> ga, 1 -> gb (C outputs over B * nblk rows of the interleaved
+// [row][2][C] partials: 4 waves x every 4th row, eight loads in flight, wave sums added in order), 2 -> dw1, 3 -> dw2 (C * C/16 outputs,
+// B rows).
+__global__ __launch_bounds__(256) void dvb_rowsum4_kernel(const float* __restrict__ part, int rows, int C, float* __restrict__ ga,
+                                                          float* __restrict__ gb, const float* __restrict__ dw1b, const float* __restrict__ dw2b,
+                                                          int B, float* __restrict__ dw1, float* __restrict__ dw2, int accumulate) {
+  const int which = blockIdx.x;
+  if (which < 2) {
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    __shared__ float sm[4][64];
+    float s = 0.f;
+    if (o < C) {
+      const float* p = part + which * C + o;
+      const long long st = 2ll * C;
+      int j = g;
+      for (; j + 28 < rows; j += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(long long)(j + 4 * u) * st];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; j < rows; j += 4) s += p[(long long)j * st];
+    }
+    sm[g][o] = s;
+    __syncthreads();
+    if (g == 0 && o < C) {
+      float* out = which ? gb : ga;
+      const float t = ((sm[0][o] + sm[1][o]) + sm[2][o]) + sm[3][o];
+      out[o] = accumulate ? out[o] + t : t;
+    }
+    return;
+  }
+  const int n = C * (C / 16);
+  const float* in = which == 2 ? dw1b : dw2b;
+  float* out = which == 2 ? dw1 : dw2;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float s = 0.f;
+    for (int j = 0; j < B; ++j) s += in[(long long)j * n + i];
+    out[i] = accumulate ? out[i] + s : s;
+  }
 }
 
 }  // namespace fcvsr
@@ -269,10 +303,7 @@ extern "C" int fcvsr_divenh_band_backward(const float* f, const float* sf, const
   hipLaunchKernelGGL(dvb_reduce_kernel<1>, dim3(nblk, B), dim3(256), 0, st, f, sf, so, a, b, gso, HW, C, part);
   hipLaunchKernelGGL(dvb_bwdmid_kernel, dim3(B), dim3(64), 0, st, part, nblk, w1, w2, stats, HW, C, bst, dw1b, dw2b);
   hipLaunchKernelGGL(dvb_bwd2_kernel, dim3(nblk, B), dim3(256), 0, st, f, sf, so, a, b, stats, bst, gsf, gso, HW, C, gf, gsf_out, gso_out, part);
-  hipLaunchKernelGGL(dvb_rowsum_kernel, dim3(1), dim3(256), 0, st, part, B * nblk, 2ll * C, C, ga, accumulate);
-  hipLaunchKernelGGL(dvb_rowsum_kernel, dim3(1), dim3(256), 0, st, part + C, B * nblk, 2ll * C, C, gb, accumulate);
-  hipLaunchKernelGGL(dvb_rowsum_kernel, dim3((C * CR + 255) / 256), dim3(256), 0, st, dw1b, B, (long long)C * CR, C * CR, dw1, accumulate);
-  hipLaunchKernelGGL(dvb_rowsum_kernel, dim3((C * CR + 255) / 256), dim3(256), 0, st, dw2b, B, (long long)C * CR, C * CR, dw2, accumulate);
+  hipLaunchKernelGGL(dvb_rowsum4_kernel, dim3(4), dim3(256), 0, st, part, B * nblk, C, ga, gb, dw1b, dw2b, B, dw1, dw2, accumulate);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

@@ -212,12 +212,39 @@ __global__ __launch_bounds__(256) void rcbt_bwd2_kernel(const float* __restrict_
   }
 }
 
-// out[i] = sum_j in[j][i] in row order (final stage of the weight-gradient sums): n elements, rows rows
-__global__ __launch_bounds__(256) void rcbt_rowsum_kernel(const float* __restrict__ in, int rows, int n, float* __restrict__ out, int accumulate) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+// The three final row sums of the backward pass in ONE launch (they were three: 108 launches per training step, the first a single
+// workgroup walking up to 256 rows one load at a time, 60 us): block 0 -> dwmask[64] over B * nblk rows (4 waves x every 4th row,
+// eight loads in flight, wave sums added in order), blocks 1 .. 16 -> dw1, 17 .. 32 -> dw2 (4096 outputs, B rows each).  Fixed order.
+__global__ __launch_bounds__(256) void rcbt_rowsum3_kernel(const float* __restrict__ part, int rows_m, float* __restrict__ dwmask,
+                                                           const float* __restrict__ dw1b, const float* __restrict__ dw2b, int B,
+                                                           float* __restrict__ dw1, float* __restrict__ dw2, int accumulate) {
+  if (blockIdx.x == 0) {
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    __shared__ float sm[4][64];
+    float s = 0.f;
+    int j = g;
+    for (; j + 28 < rows_m; j += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(long long)(j + 4 * u) * kTC + o];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; j < rows_m; j += 4) s += part[(long long)j * kTC + o];
+    sm[g][o] = s;
+    __syncthreads();
+    if (g == 0) {
+      const float t = ((sm[0][o] + sm[1][o]) + sm[2][o]) + sm[3][o];
+      dwmask[o] = accumulate ? dwmask[o] + t : t;
+    }
+    return;
+  }
+  const int blk = blockIdx.x - 1, which = blk / (kTC * kTC / 256);
+  const int i = (blk % (kTC * kTC / 256)) * 256 + threadIdx.x;
+  const float* in = which ? dw2b : dw1b;
+  float* out = which ? dw2 : dw1;
   float s = 0.f;
-  for (int j = 0; j < rows; ++j) s += in[(long long)j * n + i];
+  for (int j = 0; j < B; ++j) s += in[(long long)j * (kTC * kTC) + i];
   out[i] = accumulate ? out[i] + s : s;
 }
 
@@ -320,9 +347,8 @@ extern "C" int fcvsr_rcbt_backward(const float* r, const float* g, const float* 
   hipLaunchKernelGGL(rcbt_bwd1_kernel, dim3(nblk, B), dim3(256), 0, st, r, g, stats, slope, HW, part);
   hipLaunchKernelGGL(rcbt_bwdmid_kernel, dim3(B), dim3(64), 0, st, part, nblk, w1, w2, stats, slope, bst, dw1b, dw2b);
   hipLaunchKernelGGL(rcbt_bwd2_kernel, dim3(nblk, B), dim3(256), 0, st, r, g, wmask, stats, bst, slope, HW, gr, part);
-  hipLaunchKernelGGL(rcbt_rowsum_kernel, dim3(1), dim3(256), 0, st, part, B * nblk, kTC, dwmask, accumulate);
-  hipLaunchKernelGGL(rcbt_rowsum_kernel, dim3(kTC * kTC / 256), dim3(256), 0, st, dw1b, B, kTC * kTC, dw1, accumulate);
-  hipLaunchKernelGGL(rcbt_rowsum_kernel, dim3(kTC * kTC / 256), dim3(256), 0, st, dw2b, B, kTC * kTC, dw2, accumulate);
+  hipLaunchKernelGGL(rcbt_rowsum3_kernel, dim3(1 + 2 * (kTC * kTC / 256)), dim3(256), 0, st, part, B * nblk, dwmask, dw1b, dw2b, B, dw1, dw2,
+                     accumulate);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

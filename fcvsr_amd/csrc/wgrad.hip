@@ -108,24 +108,98 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(WgradArgs a) {
 // Threads walk the PARTIAL layout ([tap][ci][co], co fastest): every slab read is coalesced and only the n final writes are
 // scattered (with threads in dw order each lane read its own 64-byte sector per slab: 38 us for a 64 x 64 x 9 layer, 341
 // launches per training step).  Same summation order (slab 0, 1, ...) as before: bit-identical results.
+// 4 -> 4 channel layers (the multi-scale ConvBlk of MGAAbk, reference CVSR_freq.py:1284-1316: 1x1, 3x3 and 5x5 convolutions of 4-channel
+// spectra): the block kernel above spends 16 x 64 lanes on 4 x 4 channels (130 us per layer, 2.1 ms per training step).  Here a lane
+// is a PIXEL: wave w owns the taps t = w, w + 4, ... (at most 7 of 25), a lane multiplies its pixel's 4 gradient channels with the
+// 4 input channels of each of its taps (16 products per tap, f32, pixels of a slab in order), and the 64 lane sums are folded by a
+// fixed butterfly at the end.  Same partial layout and ordered final reduction as the block kernel: exact f32, bit-reproducible.
+template <int K>
+__global__ __launch_bounds__(256) void wgrad_c4_kernel(WgradArgs a) {
+  constexpr int NT = (K * K + 3) / 4, PADK = K / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slab = blockIdx.x;
+  float acc[NT][16];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  const long long p0 = (long long)slab * a.slab_pix;
+  long long p1 = p0 + a.slab_pix;
+  if (p1 > a.npix) p1 = a.npix;
+  for (long long pc = p0; pc < p1; pc += 64) {
+    const long long p = pc + lane;
+    if (p < p1) {
+      const unsigned pp = (unsigned)p;
+      const unsigned t1 = pp / (unsigned)a.W;
+      const int ox = (int)(pp - t1 * (unsigned)a.W);
+      const int b = (int)(t1 / (unsigned)a.H);
+      const int oy = (int)(t1 - (unsigned)b * (unsigned)a.H);
+      const float4 g = *reinterpret_cast<const float4*>(a.gy.p + (long long)b * a.gy.sb + (long long)oy * a.gy.sy + (long long)ox * a.gy.sx);
+      const float* xb = a.x.p + (long long)b * a.x.sb;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int tap = wave + 4 * t;
+        if (tap < K * K) {
+          const int ky = tap / K, kx = tap - ky * K;
+          const int iy = oy + ky - PADK, ix = ox + kx - PADK;
+          if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+            const float4 xv = *reinterpret_cast<const float4*>(xb + (long long)iy * a.x.sy + (long long)ix * a.x.sx);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+              for (int co = 0; co < 4; ++co) acc[t][ci * 4 + co] = fmaf(xs[ci], gs[co], acc[t][ci * 4 + co]);
+          }
+        }
+      }
+    }
+  }
+  float* pp = a.partial + (long long)slab * (K * K) * 16;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int tap = wave + 4 * t;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v = acc[t][i];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+      if (lane == 0 && tap < K * K) pp[tap * 16 + i] = v;    // [tap][ci][co]
+    }
+  }
+}
+
+// Sum of the slabs' partials in a FIXED order (bit-reproducible, no atomics): a workgroup owns 64 consecutive outputs; wave g adds
+// slabs g, g + 4, g + 8, ... in order with eight loads in flight, the four wave sums are added ((s0 + s1) + s2) + s3.
+// (Round 3: the one-thread-per-output loop over up to 256 slabs, four loads in flight, took 14-20 us per layer - 2.6 ms per step.)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
   const long long n = (long long)a.cout * a.cin * a.kh * a.kw;
-  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  const int taps = a.kh * a.kw;
-  const int co = (int)(j % a.cout);
-  const int ci = (int)((j / a.cout) % a.cin);
-  const int tap = (int)(j / ((long long)a.cout * a.cin));
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long long j = (long long)blockIdx.x * 64 + o;
+  __shared__ float part[4][64];
   float s = 0.f;
-  int sl = 0;
-  for (; sl + 4 <= a.n_slabs; sl += 4) {                 // four independent loads in flight, added in slab order
-    const float p0 = a.partial[(long long)sl * n + j], p1 = a.partial[(long long)(sl + 1) * n + j];
-    const float p2 = a.partial[(long long)(sl + 2) * n + j], p3 = a.partial[(long long)(sl + 3) * n + j];
-    s += p0; s += p1; s += p2; s += p3;
+  if (j < n) {
+    const float* p = a.partial + j;
+    int sl = g;
+    for (; sl + 28 < a.n_slabs; sl += 32) {                // slabs sl, sl + 4, ..., sl + 28
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(long long)(sl + 4 * u) * n];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; sl < a.n_slabs; sl += 4) s += p[(long long)sl * n];
   }
-  for (; sl < a.n_slabs; ++sl) s += a.partial[(long long)sl * n + j];
-  float* o = a.dw + ((long long)co * a.cin + ci) * taps + tap;
-  *o = a.accumulate ? *o + s : s;
+  part[g][o] = s;
+  __syncthreads();
+  if (g == 0 && j < n) {
+    const float t = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+    const int taps = a.kh * a.kw;
+    const int co = (int)(j % a.cout);
+    const int ci = (int)((j / a.cout) % a.cin);
+    const int tap = (int)(j / ((long long)a.cout * a.cin));
+    float* d = a.dw + ((long long)co * a.cin + ci) * taps + tap;
+    *d = a.accumulate ? *d + t : t;
+  }
 }
 
 }  // namespace fcvsr
@@ -166,10 +240,16 @@ extern "C" int fcvsr_conv2d_wgrad(const fcvsr_view* x, const fcvsr_view* gy, int
   hipStream_t st = (hipStream_t)stream;
   const int nco = (a.cout + kWgCo - 1) / kWgCo, nci = (a.cin + kWgCi - 1) / kWgCi;
   FCVSR_CHECK_ARG(kh * kw <= 65535 && (long long)nco * nci <= 65535, "grid too large");
-  hipLaunchKernelGGL(wgrad_partial_kernel, dim3(a.n_slabs, kh * kw, nco * nci), dim3(256), 0, st, a);
+  const bool c4 = a.cin == 4 && a.cout == 4 && stride == 1 && kh == kw && (kh == 1 || kh == 3 || kh == 5) && pad == kh / 2 &&
+                  ((uintptr_t)x->ptr % 16) == 0 && ((uintptr_t)gy->ptr % 16) == 0 && x->sx % 4 == 0 && x->sy % 4 == 0 && x->sb % 4 == 0 &&
+                  gy->sx % 4 == 0 && gy->sy % 4 == 0 && gy->sb % 4 == 0;
+  if (c4 && kh == 1) hipLaunchKernelGGL(wgrad_c4_kernel<1>, dim3(a.n_slabs), dim3(256), 0, st, a);
+  else if (c4 && kh == 3) hipLaunchKernelGGL(wgrad_c4_kernel<3>, dim3(a.n_slabs), dim3(256), 0, st, a);
+  else if (c4) hipLaunchKernelGGL(wgrad_c4_kernel<5>, dim3(a.n_slabs), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(wgrad_partial_kernel, dim3(a.n_slabs, kh * kw, nco * nci), dim3(256), 0, st, a);
   FCVSR_LAUNCH_CHECK();
   const long long n = (long long)a.cout * a.cin * kh * kw;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, a);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }
@@ -517,7 +597,7 @@ extern "C" int fcvsr_conv2d_wgrad_mfma(const fcvsr_view* x, const fcvsr_view* gy
   { const int e = launch_wgrad_mfma(a, grid, kh, tiles_x, tiles_y, per_slab, st); if (e) return e; }
   FCVSR_LAUNCH_CHECK();
   const long long n = (long long)a.cout * a.cin * kh * kw;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, a);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }
@@ -566,7 +646,7 @@ extern "C" int fcvsr_conv2d_wgrad_mfma_groups(const fcvsr_view* xs, const fcvsr_
   }
   a.n_slabs = slab0;
   a.partial = scratch;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, st, a);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

@@ -13,7 +13,7 @@ def _nhwc(t: torch.Tensor) -> torch.Tensor:
 
 
 class _RcbTailFn(torch.autograd.Function):
-    """R = LeakyReLU_0.2(ContextBlock(r)) + z (reference CVSR_freq.py:657-701, :722-725): three forward and six backward launches."""
+    """R = LeakyReLU_0.2(ContextBlock(r)) + z (reference CVSR_freq.py:657-701, :722-725): three forward and four backward launches."""
 
     @staticmethod
     def forward(ctx, r, z, wmask, w1, w2, slope):
@@ -69,7 +69,7 @@ def rcb_tail(r: torch.Tensor, z: torch.Tensor, wmask: torch.Tensor, w1: torch.Te
 
 class _DivEnhBandFn(torch.autograd.Function):
     """One DivEnh band (i >= 1) of MultiFreq_Refinment and its running sums (reference CVSR_freq.py:2104-2133 at :2201-2254):
-    (Sf, So) -> (Sf + f, So + e1 CA(e1) + e2 CA(e2)), three forward and seven backward launches (train_mffr.hip)."""
+    (Sf, So) -> (Sf + f, So + e1 CA(e1) + e2 CA(e2)), three forward and four backward launches (train_mffr.hip)."""
 
     @staticmethod
     def forward(ctx, f, sf, so, a, b, w1, w2):

@@ -23,12 +23,20 @@ struct WgradArgs {
   float* partial;          // [n_slabs][kh*kw][cin][cout]
   float* dw;               // [cout][cin][kh][kw]
   int accumulate;          // 1: dw += the sum (the gradient buffer was zeroed at the start of the pass), 0: dw = the sum
+  // bias gradient fused into the matrix-core form 2 (fcvsr_wgrad_set_bias_out): per-slab column sums of gy [n_slabs][cout] -> dbias
+  float* dbp;
+  float* dbias;
+  int db_accumulate;
 };
 
 // Per-thread switch of the three weight-gradient entry points between "dw = sum" and "dw += sum": the training step keeps every
 // parameter gradient in one flat, pre-zeroed buffer and lets the reduction add straight into it, which removes autograd's
 // AccumulateGrad addition per parameter and pass (fcvsr_wgrad_set_accumulate; fcvsr_amd/train/ops.py).
 static thread_local int g_wgrad_accumulate = 0;
+// One-shot request consumed by the next fcvsr_conv2d_wgrad_mfma / _groups call of this thread: also produce dL/dbias = column sums of gy
+// (f32, fixed order) - the kernel has every gy tile in registers anyway, the stand-alone column-sum launches (two per layer) go away.
+static thread_local float* g_wgrad_bias_out = nullptr;
+static thread_local int g_wgrad_bias_accumulate = 0;
 
 constexpr int kWgCo = 16, kWgCi = 64, kWgPx = 32;
 
@@ -172,13 +180,16 @@ __global__ __launch_bounds__(256) void wgrad_c4_kernel(WgradArgs a) {
 // slabs g, g + 4, g + 8, ... in order with eight loads in flight, the four wave sums are added ((s0 + s1) + s2) + s3.
 // (Round 3: the one-thread-per-output loop over up to 256 slabs, four loads in flight, took 14-20 us per layer - 2.6 ms per step.)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
-  const long long n = (long long)a.cout * a.cin * a.kh * a.kw;
+  const long long nw = (long long)a.cout * a.cin * a.kh * a.kw;
+  const long long nbw = (nw + 63) / 64;                   // blocks past these sum the bias partials [n_slabs][cout]
+  const bool isb = (long long)blockIdx.x >= nbw;
+  const long long n = isb ? a.cout : nw;
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const long long j = (long long)blockIdx.x * 64 + o;
+  const long long j = ((long long)blockIdx.x - (isb ? nbw : 0)) * 64 + o;
   __shared__ float part[4][64];
   float s = 0.f;
   if (j < n) {
-    const float* p = a.partial + j;
+    const float* p = (isb ? a.dbp : a.partial) + j;
     int sl = g;
     for (; sl + 28 < a.n_slabs; sl += 32) {                // slabs sl, sl + 4, ..., sl + 28
       float v[8];
@@ -191,7 +202,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
   }
   part[g][o] = s;
   __syncthreads();
-  if (g == 0 && j < n) {
+  if (g == 0 && j < n && isb) {
+    const float t = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+    a.dbias[j] = a.db_accumulate ? a.dbias[j] + t : t;
+  } else if (g == 0 && j < n) {
     const float t = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
     const int taps = a.kh * a.kw;
     const int co = (int)(j % a.cout);
@@ -237,6 +251,7 @@ extern "C" int fcvsr_conv2d_wgrad(const fcvsr_view* x, const fcvsr_view* gy, int
   a.slab_pix = (a.slab_pix + kWgPx - 1) / kWgPx * kWgPx;
   a.partial = scratch;
   a.dw = dw; a.accumulate = g_wgrad_accumulate;
+  a.dbp = nullptr; a.dbias = nullptr; a.db_accumulate = 0;
   hipStream_t st = (hipStream_t)stream;
   const int nco = (a.cout + kWgCo - 1) / kWgCo, nci = (a.cin + kWgCi - 1) / kWgCi;
   FCVSR_CHECK_ARG(kh * kw <= 65535 && (long long)nco * nci <= 65535, "grid too large");
@@ -428,6 +443,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WgradArgs a, int tiles
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
   const int c8 = tid & 7, ps = tid >> 3;                  // staging role: 8-channel chunk, pixel slot (32 per pass)
+  const bool do_bias = a.dbp != nullptr && ci0 == 0;      // uniform: the cin-block-0 workgroup of every cout block sums gy's columns
+  float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int b = tile / (tiles_x * tiles_y);
     const int t2 = tile - b * tiles_x * tiles_y;
@@ -466,6 +483,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WgradArgs a, int tiles
 #pragma unroll
       for (int i = 0; i < PXA; ++i) load_x(i, xv[i]);
       __syncthreads();                                   // the previous tile's images are no longer read
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < PGY; ++i) {
+          bs[0] += gv[i][0].x; bs[1] += gv[i][0].y; bs[2] += gv[i][0].z; bs[3] += gv[i][0].w;
+          bs[4] += gv[i][1].x; bs[5] += gv[i][1].y; bs[6] += gv[i][1].z; bs[7] += gv[i][1].w;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < PGY; ++i) store_rec(gy_s, i * 32 + ps, gv[i]);
 #pragma unroll
@@ -519,6 +543,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WgradArgs a, int tiles
       *reinterpret_cast<float4*>(pp + ((long long)t * a.cin + ci) * a.cout + co) =
           make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
     }
+  if (do_bias) {                                         // 32 pixel slots x 64 channels -> 64 column sums of this slab, slots in order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(gy_s);
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) red[ps * 64 + c8 * 8 + jj] = bs[jj];
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+      for (int rr = 0; rr < 32; ++rr) t += red[rr * 64 + tid];
+      a.dbp[(long long)slab * a.cout + co0 + tid] = t;
+    }
+  }
 }
 
 }  // namespace fcvsr
@@ -564,7 +600,17 @@ static int launch_wgrad_mfma(const WgradArgs& a, dim3 grid, int kh, int tiles_x,
 }
 
 extern "C" long long fcvsr_conv2d_wgrad_mfma_scratch_elems(int B, int Ho, int Wo, int cin, int cout, int kh, int kw) {
-  return (long long)wgrad_mfma_slabs(B, Ho, Wo, cin, cout) * kh * kw * cin * cout;
+  return (long long)wgrad_mfma_slabs(B, Ho, Wo, cin, cout) * ((long long)kh * kw * cin * cout + cout);      // + the bias partials
+}
+
+/* One-shot: the next fcvsr_conv2d_wgrad_mfma / fcvsr_conv2d_wgrad_mfma_groups call of this thread also writes (accumulate = 0) or adds
+ * (1) dL/dbias = sum over pixels of gy into dbias[cout].  Returns 1 when the build's weight-gradient form supports it (form 2), else 0
+ * (the request is then ignored: use fcvsr_colsum). */
+extern "C" int fcvsr_wgrad_set_bias_out(float* dbias, int accumulate) {
+  static const int form = getenv("FCVSR_WGRAD_FORM") ? atoi(getenv("FCVSR_WGRAD_FORM")) : 2;
+  if (form != 2) return 0;
+  g_wgrad_bias_out = dbias; g_wgrad_bias_accumulate = accumulate ? 1 : 0;
+  return 1;
 }
 
 extern "C" int fcvsr_conv2d_wgrad_mfma_eligible(int cin, int cout, int kh, int kw, int stride, int pad) {
@@ -586,9 +632,13 @@ extern "C" int fcvsr_conv2d_wgrad_mfma(const fcvsr_view* x, const fcvsr_view* gy
   a.Ho = H; a.Wo = W; a.cin = x->c; a.cout = gy->c;
   a.npix = (long long)B * H * W;
   a.n_slabs = wgrad_mfma_slabs(B, H, W, a.cin, a.cout);
-  FCVSR_CHECK_ARG(scratch_elems >= (long long)a.n_slabs * kh * kw * a.cin * a.cout, "scratch too small (fcvsr_conv2d_wgrad_mfma_scratch_elems)");
+  float* const bias_out = g_wgrad_bias_out;
+  g_wgrad_bias_out = nullptr;                            // one-shot
+  FCVSR_CHECK_ARG(scratch_elems >= (long long)a.n_slabs * ((long long)kh * kw * a.cin * a.cout + a.cout), "scratch too small (fcvsr_conv2d_wgrad_mfma_scratch_elems)");
   a.slab_pix = 0;
   a.partial = scratch; a.dw = dw; a.accumulate = g_wgrad_accumulate;
+  a.dbp = bias_out ? scratch + (long long)a.n_slabs * kh * kw * a.cin * a.cout : nullptr;
+  a.dbias = bias_out; a.db_accumulate = g_wgrad_bias_accumulate;
   const int tiles_x = cdiv(W, kGTX), tiles_y = cdiv(H, kGTY);
   const int total = B * tiles_x * tiles_y;
   const int per_slab = (total + a.n_slabs - 1) / a.n_slabs;
@@ -597,7 +647,7 @@ extern "C" int fcvsr_conv2d_wgrad_mfma(const fcvsr_view* x, const fcvsr_view* gy
   { const int e = launch_wgrad_mfma(a, grid, kh, tiles_x, tiles_y, per_slab, st); if (e) return e; }
   FCVSR_LAUNCH_CHECK();
   const long long n = (long long)a.cout * a.cin * kh * kw;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64 + (a.dbp ? (a.cout + 63) / 64 : 0))), dim3(256), 0, st, a);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }
@@ -609,7 +659,7 @@ extern "C" long long fcvsr_conv2d_wgrad_mfma_groups_scratch_elems(const int* B, 
                                                                   int kh, int kw) {
   long long slabs = 0;
   for (int g = 0; g < n_groups; ++g) slabs += wgrad_mfma_slabs(B[g], H[g], W[g], cin, cout);
-  return slabs * kh * kw * cin * cout;
+  return slabs * ((long long)kh * kw * cin * cout + cout);
 }
 
 extern "C" int fcvsr_conv2d_wgrad_mfma_groups(const fcvsr_view* xs, const fcvsr_view* gys, const int* B, const int* H, const int* W, int n_groups,
@@ -620,7 +670,12 @@ extern "C" int fcvsr_conv2d_wgrad_mfma_groups(const fcvsr_view* xs, const fcvsr_
   FCVSR_CHECK_ARG(fcvsr_conv2d_wgrad_mfma_eligible(cin, cout, kh, kw, 1, pad), "layer not eligible for the matrix-core weight gradient");
   const long long per = (long long)kh * kw * cin * cout;
   hipStream_t st = (hipStream_t)stream;
-  int slab0 = 0;
+  int slab0 = 0, slabs_total = 0;
+  for (int g = 0; g < n_groups; ++g) slabs_total += wgrad_mfma_slabs(B[g], H[g], W[g], cin, cout);
+  float* const bias_out = g_wgrad_bias_out;
+  g_wgrad_bias_out = nullptr;                            // one-shot
+  FCVSR_CHECK_ARG(scratch_elems >= (long long)slabs_total * (per + cout), "scratch too small (fcvsr_conv2d_wgrad_mfma_groups_scratch_elems)");
+  float* const dbp_all = bias_out ? scratch + (long long)slabs_total * per : nullptr;
   WgradArgs a;
   for (int g = 0; g < n_groups; ++g) {
     const fcvsr_view* x = xs + g, *gy = gys + g;
@@ -636,6 +691,7 @@ extern "C" int fcvsr_conv2d_wgrad_mfma_groups(const fcvsr_view* xs, const fcvsr_
     FCVSR_CHECK_ARG(scratch_elems >= (long long)(slab0 + a.n_slabs) * per, "scratch too small (fcvsr_conv2d_wgrad_mfma_groups_scratch_elems)");
     a.slab_pix = 0;
     a.partial = scratch + (long long)slab0 * per; a.dw = dw; a.accumulate = g_wgrad_accumulate;
+    a.dbp = dbp_all ? dbp_all + (long long)slab0 * cout : nullptr; a.dbias = bias_out; a.db_accumulate = g_wgrad_bias_accumulate;
     const int tiles_x = cdiv(W[g], kGTX), tiles_y = cdiv(H[g], kGTY);
     const int total = B[g] * tiles_x * tiles_y;
     const int per_slab = (total + a.n_slabs - 1) / a.n_slabs;
@@ -646,7 +702,8 @@ extern "C" int fcvsr_conv2d_wgrad_mfma_groups(const fcvsr_view* xs, const fcvsr_
   }
   a.n_slabs = slab0;
   a.partial = scratch;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, st, a);
+  a.dbp = dbp_all;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 63) / 64 + (dbp_all ? (cout + 63) / 64 : 0))), dim3(256), 0, st, a);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

@@ -128,6 +128,7 @@ SIGNATURES = {
     "fcvsr_prelu_bwd": [_VP, _VP, _VP, _VP, _VP, _VP, C.c_longlong, _VP],
     "fcvsr_wgrad_cout1_scratch_elems": [_I, _I, _I],
     "fcvsr_wgrad_cout1": [_VP, _VP, _I, _I, _I, _I, _VP, _VP, C.c_longlong, _VP],
+    "fcvsr_wgrad_set_bias_out": [_VP, _I],
     "fcvsr_conv2d_wgrad_mfma_groups_scratch_elems": [_VP, _VP, _VP, _I, _I, _I, _I, _I],
     "fcvsr_conv2d_wgrad_mfma_groups": [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, C.c_longlong, _VP],
     "fcvsr_colsum_groups_scratch_elems": [_VP, _I, _I],

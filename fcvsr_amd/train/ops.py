@@ -170,6 +170,7 @@ class _Conv2dFn(torch.autograd.Function):
                 g_in[:, ::stride, ::stride, :][:, :gyv.shape[1], :gyv.shape[2]] = gyv
             gx = _run_conv(g_in, w, None, 1, precision, transposed=True).permute(0, 3, 1, 2)
         sink = _grad_sink(w) if ctx.needs_input_grad[1] else None      # add into the flat gradient buffer in place?
+        fused_bias, gb_f, bsink_f = False, None, None
         if sink is not None:
             L.fcvsr_wgrad_set_accumulate(1)
             L.fcvsr_colsum_set_accumulate(1)
@@ -190,6 +191,11 @@ class _Conv2dFn(torch.autograd.Function):
                 gw = sink if sink is not None else torch.empty((cout, cin, k, k), dtype=torch.float32, device=xv.device)
                 xd, gd = hip.view(xv), hip.view(gyv)
                 fn = L.fcvsr_conv2d_wgrad_mfma if mm else L.fcvsr_conv2d_wgrad
+                if mm and ctx.has_bias and ctx.needs_input_grad[2]:
+                    # the matrix-core kernel has every gy tile in registers: it also sums gy's columns (the bias gradient)
+                    bsink_f = _grad_sink(bias)
+                    gb_f = bsink_f if bsink_f is not None else torch.empty(cout, dtype=torch.float32, device=xv.device)
+                    fused_bias = bool(L.fcvsr_wgrad_set_bias_out(gb_f.data_ptr(), 1 if bsink_f is not None else 0))
                 hip.check(fn(C.addressof(xd), C.addressof(gd), B, H, W, k, k, stride, k // 2, gw.data_ptr(), scratch.data_ptr(), n,
                              hip.stream_ptr()), "fcvsr_conv2d_wgrad")
         finally:
@@ -197,7 +203,9 @@ class _Conv2dFn(torch.autograd.Function):
                 L.fcvsr_wgrad_set_accumulate(0)
                 L.fcvsr_colsum_set_accumulate(0)
                 gw = None                                             # already in w.grad
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if fused_bias:
+            gb = None if bsink_f is not None else gb_f
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
             bsink = _grad_sink(bias)
             if bsink is not None:
                 L.fcvsr_colsum_set_accumulate(1)
@@ -264,6 +272,7 @@ class _ConvLevelsFn(torch.autograd.Function):
             hip.conv2d_mfma([dict(srcs=[gv], dst=o) for gv, o in zip(gvs, gx)], packed_weight_mfma(w, tdt, True), k, cin, mdt)
             gxs = [o.permute(0, 3, 1, 2) for o in gx]
         gw = gb = None
+        fused_bias, gb_f, bsink_f = False, None, None
         if ctx.needs_input_grad[0]:
             Bs = (C.c_int * n)(*[xv.shape[0] for xv in xvs])
             Hs = (C.c_int * n)(*[xv.shape[1] for xv in xvs])
@@ -275,6 +284,10 @@ class _ConvLevelsFn(torch.autograd.Function):
             xd = (hip.View * n)(*[hip.view(xv) for xv in xvs])
             gd = (hip.View * n)(*[hip.view(gv) for gv in gvs])
             L.fcvsr_wgrad_set_accumulate(1 if sink is not None else 0)
+            if ctx.has_bias and ctx.needs_input_grad[1]:
+                bsink_f = _grad_sink(bias)
+                gb_f = bsink_f if bsink_f is not None else torch.empty(cout, dtype=torch.float32, device=w.device)
+                fused_bias = bool(L.fcvsr_wgrad_set_bias_out(gb_f.data_ptr(), 1 if bsink_f is not None else 0))
             try:
                 hip.check(L.fcvsr_conv2d_wgrad_mfma_groups(xd, gd, Bs, Hs, Ws, n, k, k, k // 2, gw.data_ptr(), scratch.data_ptr(), ne, st),
                           "fcvsr_conv2d_wgrad_mfma_groups")
@@ -282,7 +295,9 @@ class _ConvLevelsFn(torch.autograd.Function):
                 L.fcvsr_wgrad_set_accumulate(0)
             if sink is not None:
                 gw = None
-        if ctx.has_bias and ctx.needs_input_grad[1]:
+        if fused_bias:
+            gb = None if bsink_f is not None else gb_f
+        elif ctx.has_bias and ctx.needs_input_grad[1]:
             ptrs = (C.c_void_p * n)(*[gv.data_ptr() for gv in gvs])
             npx = (C.c_longlong * n)(*[gv.numel() // cout for gv in gvs])
             ne = L.fcvsr_colsum_groups_scratch_elems(npx, n, cout)

@@ -174,6 +174,12 @@ int fcvsr_iac_bwd_sac(const float* gy, const float* yout, const float* v, const 
                       int W, int C, float* gfin, int fin_accumulate, float* gv, const fcvsr_view* gk, int k_accumulate, void* stream);
 int fcvsr_iac_bwd_warp(const float* gv, const fcvsr_view* k1, const float* prev, const fcvsr_view* off, int B, int H, int W, int C,
                        float* gprev_zeroed, float* goff, void* stream);
+/* One-shot request consumed by the next fcvsr_conv2d_wgrad_mfma / fcvsr_conv2d_wgrad_mfma_groups call of the calling thread: also write
+ * (accumulate = 0) or add (1) dL/dbias[cout] = sum over pixels of gy (nn.Conv2d bias gradient; f32, fixed summation order) - the kernel
+ * has the gy tiles in registers, the separate fcvsr_colsum launches go away.  Returns 1 if the weight-gradient form in use supports it
+ * (default form), 0 otherwise (request ignored). */
+int fcvsr_wgrad_set_bias_out(float* dbias, int accumulate);
+
 /* fcvsr_conv2d_wgrad_mfma summed over 1..3 problems that share the weight (the pyramid levels of a BlockRCB layer): one launch per
  * problem into consecutive slab ranges of one scratch buffer and ONE ordered reduction (no per-level gradient tensors). */
 long long fcvsr_conv2d_wgrad_mfma_groups_scratch_elems(const int* B, const int* H, const int* W, int n_groups, int cin, int cout, int kh,

@@ -654,7 +654,11 @@ static hipError_t launch_res(const ResArgs& a, hipStream_t st) {
   if (e != hipSuccess) return e;
   const int cus = device_cu_count(dev);
   if (cus <= 0) return hipErrorInvalidDevice;
-  const int n_cu = cus > 8 ? cus / 8 * 8 : 8;
+  int n_cu = cus > 8 ? cus / 8 * 8 : 8;
+  {                                                      // experiment: leave CUs to the other stream's kernels (FCVSR_RES_CUS < CU count)
+    static const int lim = getenv("FCVSR_RES_CUS") ? atoi(getenv("FCVSR_RES_CUS")) : 0;
+    if (lim >= 8 && lim < n_cu) n_cu = lim / 8 * 8;
+  }
   const int NB = a.cout / (64 / NCH);
   // one persistent workgroup per CU; the grid is a multiple of 8 * NB (every XCD gets whole slots of NB cout blocks)
   int grid = n_cu / (8 * NB) * (8 * NB);

@@ -27,6 +27,36 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
   }
 }
 
+// Every planned weight of a training pass in ONE launch (the per-weight launches were 205 per step, 0.74 ms): tab[item] = {src, dst,
+// cout, cin, kk, rows_pad, cols_pad, transposed, first block}; a block packs kPwmElems consecutive elements of its item.
+constexpr int kPwmElems = 2048;
+template <bool BF16>
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const long long* __restrict__ tab, int n_items) {
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {                                        // last item whose first block is <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid * 9 + 8] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long long* it = tab + lo * 9;
+  const float* w = reinterpret_cast<const float*>(it[0]);
+  uint16_t* dst = reinterpret_cast<uint16_t*>(it[1]);
+  const int cout = (int)it[2], cin = (int)it[3], kk = (int)it[4], rows_pad = (int)it[5], cols_pad = (int)it[6], transposed = (int)it[7];
+  const long long total = (long long)kk * rows_pad * cols_pad;
+  const long long e0 = ((long long)blockIdx.x - it[8]) * kPwmElems;
+  for (long long i = e0 + threadIdx.x; i < e0 + kPwmElems && i < total; i += 256) {
+    const int col = (int)(i % cols_pad);
+    const long long t = i / cols_pad;
+    const int row = (int)(t % rows_pad), tap = (int)(t / rows_pad);
+    const int co = transposed ? col : row, ci = transposed ? row : col;
+    float v = 0.f;
+    if (co < cout && ci < cin) v = w[((long long)co * cin + ci) * kk + (transposed ? kk - 1 - tap : tap)];
+    uint16_t o;
+    if (BF16) { const __bf16 b = (__bf16)v; o = __builtin_bit_cast(uint16_t, b); }
+    else { const _Float16 hh = (_Float16)v; o = __builtin_bit_cast(uint16_t, hh); }
+    dst[i] = o;
+  }
+}
+
 // g_pre = g * act'(y) with y the activation's OUTPUT (LeakyReLU / ReLU: the sign of y is the sign of the pre-activation for a
 // positive slope; for slope 0 the y == 0 entries take the zero-side derivative like torch's threshold_backward).  4 floats per lane.
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float4* __restrict__ g, const float4* __restrict__ y, float4* __restrict__ out,
@@ -223,6 +253,19 @@ extern "C" int fcvsr_pack_weight_mfma(const float* w, int cout, int cin, int kh,
     hipLaunchKernelGGL(pack_weight_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)dst, cout, cin, kh * kw, rows_pad, cols_pad, transposed);
   else
     hipLaunchKernelGGL(pack_weight_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)dst, cout, cin, kh * kw, rows_pad, cols_pad, transposed);
+  FCVSR_LAUNCH_CHECK();
+  return 0;
+}
+
+/* fcvsr_pack_weight_mfma for n_items weights in one launch.  tab (device memory, 9 x int64 per item): source pointer (f32, contiguous
+ * (cout,cin,kh,kw)), destination pointer, cout, cin, kh*kw, rows_pad, cols_pad, transposed, first block; item i owns the blocks
+ * [first_i, first_i + ceil(kh*kw*rows_pad*cols_pad / fcvsr_pack_weights_multi_block_elems())); total_blocks = their sum. */
+extern "C" int fcvsr_pack_weights_multi_block_elems(void) { return kPwmElems; }
+extern "C" int fcvsr_pack_weights_mfma_multi(const long long* tab, int n_items, int total_blocks, int dtype, void* stream) {
+  FCVSR_CHECK_ARG(tab && n_items >= 1 && total_blocks >= 1, "empty plan");
+  FCVSR_CHECK_ARG(dtype == FCVSR_BF16 || dtype == FCVSR_F16, "16-bit destination only");
+  if (dtype == FCVSR_BF16) hipLaunchKernelGGL(pack_weight_multi_kernel<true>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, tab, n_items);
+  else hipLaunchKernelGGL(pack_weight_multi_kernel<false>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, tab, n_items);
   FCVSR_LAUNCH_CHECK();
   return 0;
 }

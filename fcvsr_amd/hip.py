@@ -119,6 +119,8 @@ SIGNATURES = {
     "fcvsr_tail_fused": [_PV, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _PV, _VP],
     "fcvsr_conv_last": [_PV, _VP, _VP, _I, _I, _I, _I, _PV, _VP],
     "fcvsr_pack_weight_mfma": [_VP, _I, _I, _I, _I, _VP, _I, _I, _I, _I, _VP],
+    "fcvsr_pack_weights_multi_block_elems": [],
+    "fcvsr_pack_weights_mfma_multi": [_VP, _I, _I, _I, _VP],
     "fcvsr_act_bwd": [_VP, _VP, _VP, _F, C.c_longlong, _VP],
     "fcvsr_colsum_scratch_elems": [C.c_longlong, _I],
     "fcvsr_colsum": [_VP, C.c_longlong, _I, _VP, _VP, C.c_longlong, _VP],

@@ -294,7 +294,8 @@ def forward_train(p: Dict[str, Tensor], x: Tensor, *, precision: str = "f32", fu
     # layer applied several times packs once).  Across passes the cache must not survive: the optimizer rewrites every weight, and a
     # freed model's storage can be handed to another parameter of the same shape and version.  Clearing here also guarantees that a
     # hipGraph capture records the packing kernels of its pass.
-    clear_packed_weights()
+    first, last = next(iter(p.values())), p["conv_last0.weight"]
+    clear_packed_weights(owner=(first.data_ptr(), last.data_ptr(), len(p), precision, str(first.device)))
     c = _Ctx(p, precision, fused_blocks)
     x7 = x.reshape(B, T * C, H, W).float()
     if precision == "f32" or (T * C) % 64 == 0:

@@ -18,6 +18,7 @@ gradient) are one launch each, cached per parameter version - they were chains o
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -62,9 +63,58 @@ def _grad_sink(p: Optional[torch.Tensor]):
     return g
 
 
-def clear_packed_weights() -> None:
-    """Forget every cached operand packing (called at the start of each differentiable forward: see graph.forward_train)."""
+# The packings one pass asked for (leaf parameters only: their storage is stable), recorded during a pass and replayed as ONE launch
+# at the start of the next ones (fcvsr_pack_weights_mfma_multi): items = [(weight, dtype, transposed, packed tensor)], table on the device.
+_PLAN = None                         # dict(items=..., tabs={dtype: (table tensor, n_items, total_blocks)}, device=...)
+_RECORD = []                         # requests of the pass in progress (while no plan exists)
+_PLAN_ENABLED = os.environ.get("FCVSR_PACK_PLAN", "1") == "1"
+
+
+def _build_plan(items):
+    dev = items[0][0].device
+    be = hip.lib().fcvsr_pack_weights_multi_block_elems()
+    tabs = {}
+    for tdt in set(it[1] for it in items):
+        rows, blk = [], 0
+        for (w, t, transposed, out) in items:
+            if t != tdt:
+                continue
+            cout, cin, kh, kw = w.shape
+            kk, rp, cp = out.shape
+            rows.append([w.data_ptr(), out.data_ptr(), cout, cin, kk, rp, cp, int(transposed), blk])
+            blk += (kk * rp * cp + be - 1) // be
+        tabs[tdt] = (torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), blk)
+    return dict(items=items, tabs=tabs, device=dev, ptrs=[it[0].data_ptr() for it in items])
+
+
+_OWNER = None                        # whose passes _RECORD / _PLAN belong to (forward_train passes a key of its parameter set)
+
+
+def clear_packed_weights(owner=None) -> None:
+    """Start of a differentiable pass (graph.forward_train): forget the cached operand packings; when the previous pass of the SAME
+    parameter set left a plan (same storage), re-pack all of its weights from their current values in one launch."""
+    global _PLAN, _RECORD, _OWNER
     _PACKED.clear()
+    if not _PLAN_ENABLED:
+        return
+    if owner != _OWNER:                                   # another model: drop the plan (and its references), record afresh
+        _PLAN, _RECORD, _OWNER = None, [], owner
+        return
+    if _PLAN is None and _RECORD and not torch.cuda.is_current_stream_capturing():
+        _PLAN = _build_plan(_RECORD)                      # (uploads the table: never inside a capture)
+    _RECORD = []
+    if _PLAN is None:
+        return
+    items = _PLAN["items"]
+    if any(w.data_ptr() != ptr or w.dtype != torch.float32 or not w.is_contiguous() or w.device != _PLAN["device"]
+           for (w, _, _, _), ptr in zip(items, _PLAN["ptrs"])):
+        _PLAN = None                                      # parameters moved: record again during this pass
+        return
+    L = hip.lib()
+    for tdt, (tab, n, blocks) in _PLAN["tabs"].items():
+        hip.check(L.fcvsr_pack_weights_mfma_multi(tab.data_ptr(), n, blocks, hip._DT[tdt], hip.stream_ptr()), "fcvsr_pack_weights_mfma_multi")
+    for (w, tdt, transposed, out) in items:
+        _PACKED[(w.data_ptr(), w._version, tdt, transposed, tuple(w.shape), str(w.device))] = out
 
 
 def _nhwc(t: torch.Tensor) -> torch.Tensor:
@@ -90,6 +140,8 @@ def packed_weight_mfma(w: torch.Tensor, tdt: torch.dtype, transposed: bool) -> t
     hip.check(hip.lib().fcvsr_pack_weight_mfma(wd.data_ptr(), cout, cin, kh, kw, out.data_ptr(), rp, cp, hip._DT[tdt], int(transposed),
                                                hip.stream_ptr()), "fcvsr_pack_weight_mfma")
     _PACKED[key] = out
+    if _PLAN_ENABLED and _PLAN is None and w.is_leaf and wd.data_ptr() == w.data_ptr():
+        _RECORD.append((w, tdt, transposed, out))         # a parameter in stable storage: part of the next passes' one-launch packing
     return out
 
 

@@ -120,6 +120,11 @@ int fcvsr_conv2d_wgrad_mfma(const fcvsr_view* x, const fcvsr_view* gy, int B, in
  * fcvsr_colsum: out[c] = sum over the npix rows of a dense (npix, C) f32 matrix (bias gradient), deterministic two-stage. */
 int fcvsr_pack_weight_mfma(const float* w, int cout, int cin, int kh, int kw, void* dst, int rows_pad, int cols_pad, int dtype,
                            int transposed, void* stream);
+/* The same packing for n_items weights in ONE launch (a training pass re-packs ~200 weights).  tab: device memory, 9 x int64 per item =
+ * {source pointer (f32 contiguous (cout,cin,kh,kw)), destination pointer, cout, cin, kh*kw, rows_pad, cols_pad, transposed, first block};
+ * item i owns ceil(kh*kw*rows_pad*cols_pad / fcvsr_pack_weights_multi_block_elems()) consecutive blocks; total_blocks = their sum. */
+int fcvsr_pack_weights_multi_block_elems(void);
+int fcvsr_pack_weights_mfma_multi(const long long* tab, int n_items, int total_blocks, int dtype, void* stream);
 int fcvsr_act_bwd(const float* g, const float* y, float* out, float slope, long long n, void* stream);
 long long fcvsr_colsum_scratch_elems(long long npix, int C);
 int fcvsr_colsum(const float* x, long long npix, int C, float* out, float* scratch, long long scratch_elems, void* stream);

@@ -683,14 +683,17 @@ struct Iac2Args {        // compact: both directions share every stride (host-ch
 #ifndef FCVSR_IAC2_EARLY
 #define FCVSR_IAC2_EARLY 2
 #endif
-// NG = 2: a workgroup of 8 waves walks TWO tiles at a time (wave group g = waves 4g .. 4g+3, its own s / v tile) over one copy
-// of the predictor weights: 74.6 KB per 8 waves, two workgroups = 16 waves per CU (the 4-wave form: 49.9 KB, 12 waves per CU).
-template <int KDT, int ADT, int NG>
-__global__ __launch_bounds__(256 * NG, NG == 2 ? 2 : FCVSR_IAC2_WGS) void iac_fused2_kernel(Iac2Args a) {
+// (Tried and dropped, round 3: 8-wave workgroups - two 4-row tiles over one weight copy, 16 waves per CU: 252 vs 248 us; one 8-row tile
+// (warped halo 1.43 instead of 1.71 pixels per output pixel) needs <= 128 registers for two workgroups per CU and spilled 49.)
+template <int KDT, int ADT>
+__global__ __launch_bounds__(256, FCVSR_IAC2_WGS) void iac_fused2_kernel(Iac2Args a) {
+  constexpr int NG = 1;
   static_assert(ADT != FCVSR_F32 && KDT != FCVSR_F32, "16-bit form");
   constexpr bool BF = KDT == FCVSR_BF16;
-  constexpr int ND = 2, NP = kQNS / 32;                  // 3 gather passes of 32 pixel slots
-  __shared__ __align__(16) float s_all[NG * kQNS * kJC]; // 24,576 B per wave group; v = records 0..63
+  constexpr int SPP = 32 * NG;                           // pixel slots per gather pass
+  constexpr int ND = 2, NP = (kQNS + SPP - 1) / SPP;     // 3 gather passes
+  constexpr int EARLY = FCVSR_IAC2_EARLY;                // passes of direction 1 requested before direction 0's LDS phases
+  __shared__ __align__(16) float s_all[kQNS * kJC];      // 24,576 B (4 rows) / 40,960 B (8 rows); v = the first kQY * 16 records
   __shared__ __align__(16) uint16_t w_s[3 * kJC * kJC];  // 24,576 B, 16-byte segments XOR (row & 7)
   __shared__ __align__(16) float kb_s[3 * kJC];
   const float slope = a.slope;
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 2 : FCVSR_IAC2_WGS) void iac_fu
     const int bb = tt / (tiles_x * tiles_y), tt2 = tt - bb * tiles_x * tiles_y;
     const int oy0 = (tt2 / tiles_x) * kQY, ox0 = (tt2 % tiles_x) * kQX;
     const int sdir = lanev >> 5, sit = (lanev >> 3) & 3, spl = lanev & 7;
-    int hp = sit * 32 + wavev * 8 + spl;
+    int hp = sit * SPP + wavev * 8 + spl;
     hp = hp < kQNS ? hp : kQNS - 1;
     const int hy = hp >> 4, hx = hp & 15;
     int gy = oy0 + hy - 1, gx = ox0 + hx - 1;
@@ -731,20 +734,12 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 2 : FCVSR_IAC2_WGS) void iac_fu
     const float* op = (sdir ? a.off[1] : a.off[0]) + (long long)bb * a.off_sb + (gy * a.off_sy + gx * a.off_sx);
     return make_float2(op[0], op[a.off_sc]);
   };
-  const int wave_a = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int wave_s = wave_a & 3, grp = wave_a >> 2;      // row of the tile, wave group (scalars)
-  float* const s_s = s_all + grp * (kQNS * kJC);
+  const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // row of the tile (scalar)
+  float* const s_s = s_all;
   float* const v_s = s_s;
   float2 off_next = make_float2(0.f, 0.f);
-  {
-    int t0 = t_begin + grp;
-    t0 = t0 < t_end ? t0 : t_end - 1;
-    if (t_begin < t_end) off_next = load_off(t0, (int)threadIdx.x & 255);
-  }
-  for (int tb = t_begin; tb < t_end; tb += NG) {
-    // a group past the end of the run repeats the last tile with its stores switched off: every wave meets every barrier
-    const bool live = tb + grp < t_end;
-    const int t = live ? tb + grp : t_end - 1;
+  if (t_begin < t_end) off_next = load_off(t_begin, (int)threadIdx.x);
+  for (int t = t_begin; t < t_end; ++t) {
     // thread id = scalar wave index * 64 + lane (mbcnt): recomputed per tile, no vector register carried around the loop
     int tid;                                             // volatile asm: not hoisted out of the tile loop (where it would be spilled)
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshl_add_u32 %0, %1, 6, %0" : "=&v"(tid) : "s"(wave_s));
@@ -782,7 +777,7 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 2 : FCVSR_IAC2_WGS) void iac_fu
     {
       const int x = fresh(), lane = x & 63;
       const int sit = (lane >> 3) & 3, spl = lane & 7;
-      int hp = sit * 32 + wave * 8 + spl;
+      int hp = sit * SPP + wave * 8 + spl;
       hp = hp < kQNS ? hp : kQNS - 1;
       const int hy = hp >> 4, hx = hp & 15;
       int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
@@ -835,7 +830,7 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 2 : FCVSR_IAC2_WGS) void iac_fu
       const int x = fresh(), oct = x & 7, ps = x >> 3, pull = ((x & 63) >> 3) << 2;
 #pragma unroll
       for (int it = 0; it < NP; ++it) {
-        const int hp = it * 32 + ps;
+        const int hp = it * SPP + ps;
         const int src = pull + dir * 128 + it * 32;
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float tw[4];
@@ -850,8 +845,10 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 2 : FCVSR_IAC2_WGS) void iac_fu
           for (int c = 0; c < 8; ++c) acc[c] = fmaf(v[c], w, acc[c]);
         }
         float* rec = s_s + hp * kJC;
-        *reinterpret_cast<float4*>(rec + (((2 * oct) ^ (hp & 15)) << 2)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        *reinterpret_cast<float4*>(rec + (((2 * oct + 1) ^ (hp & 15)) << 2)) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        if (kQNS % SPP == 0 || hp < kQNS) {
+          *reinterpret_cast<float4*>(rec + (((2 * oct) ^ (hp & 15)) << 2)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+          *reinterpret_cast<float4*>(rec + (((2 * oct + 1) ^ (hp & 15)) << 2)) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -916,7 +913,7 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 2 : FCVSR_IAC2_WGS) void iac_fu
       // ---- horizontal (kernel1 again) + residual + LeakyReLU ----
       const int x = fresh(), n = x & 15, q = (x & 63) >> 4;
       const int gx = tx0 + n - 1;
-      if (n >= 1 && n <= kQX && row < H && gx < W && live) {
+      if (n >= 1 && n <= kQX && row < H && gx < W) {
         uint16_t* const db = a.dst[dir] + (long long)b * a.dst_sb + (long long)row * a.dst_sy;
         const int e = gx * a.dst_sx + q * 16;
 #pragma unroll
@@ -951,18 +948,14 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 2 : FCVSR_IAC2_WGS) void iac_fu
     __builtin_amdgcn_sched_barrier(0);
     warp_store(0);
     __builtin_amdgcn_sched_barrier(0);
-    issue_taps(1, 0, FCVSR_IAC2_EARLY);                  // in flight during direction 0's LDS phases
+    issue_taps(1, 0, EARLY);                  // in flight during direction 0's LDS phases
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     sac(0);
-    issue_taps(1, FCVSR_IAC2_EARLY, NP);
+    issue_taps(1, EARLY, NP);
     // the next tile's offsets head its longest dependency chain (offsets -> addresses -> gather): requested here, where few
     // registers are live (before direction 0's phases the two values were spilled, and the spill waited for every gather)
-    if (tb + NG < t_end) {
-      int tn = tb + NG + grp;
-      tn = tn < t_end ? tn : t_end - 1;
-      off_next = load_off(tn, fresh());
-    }
+    if (t + 1 < t_end) off_next = load_off(t + 1, fresh());
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                                     // v of direction 0 has been read: s may be rewritten
     warp_store(1);
@@ -1150,20 +1143,11 @@ extern "C" int fcvsr_iac_step2_fused(const fcvsr_view* prev, const fcvsr_view* o
     q.fin_sy = (int)feat_in[0].sy; q.fin_sx = (int)feat_in[0].sx; q.dst_sy = (int)dst[0].sy; q.dst_sx = (int)dst[0].sx;
     q.k0_sy = (int)k0->sy; q.k0_sx = (int)k0->sx;
     q.slope = slope; q.H = H; q.W = W; q.tiles_x = cdiv(W, kQX); q.tiles_y = cdiv(H, kQY); q.ntiles = B * q.tiles_x * q.tiles_y;
-    static const int ng = getenv("FCVSR_IAC_NG") ? atoi(getenv("FCVSR_IAC_NG")) : 1;   // 2: measured equal (252 vs 248 us): not the default
-    if (ng == 2 && adt == FCVSR_BF16) {                  // 8 waves per workgroup, two per CU (the f16 form needs 136 registers: 4-wave form)
-      int nwg = iac_persistent_wgs();
-      nwg = nwg < 8 ? 8 : nwg / 8 * 8;
-      if (nwg > (q.ntiles + 1) / 2) nwg = (q.ntiles + 1) / 2;
-      hipLaunchKernelGGL((iac_fused2_kernel<FCVSR_BF16, FCVSR_BF16, 2>), dim3(nwg), dim3(512), 0, st, q);
-      FCVSR_LAUNCH_CHECK();
-      return 0;
-    }
     int nwg = iac_persistent_wgs() / 2 * FCVSR_IAC2_WGS;
     nwg = nwg < 8 ? 8 : nwg / 8 * 8;
     if (nwg > q.ntiles) nwg = q.ntiles;
-    if (adt == FCVSR_BF16) hipLaunchKernelGGL((iac_fused2_kernel<FCVSR_BF16, FCVSR_BF16, 1>), dim3(nwg), dim3(256), 0, st, q);
-    else hipLaunchKernelGGL((iac_fused2_kernel<FCVSR_F16, FCVSR_F16, 1>), dim3(nwg), dim3(256), 0, st, q);
+    if (adt == FCVSR_BF16) hipLaunchKernelGGL((iac_fused2_kernel<FCVSR_BF16, FCVSR_BF16>), dim3(nwg), dim3(256), 0, st, q);
+    else hipLaunchKernelGGL((iac_fused2_kernel<FCVSR_F16, FCVSR_F16>), dim3(nwg), dim3(256), 0, st, q);
     FCVSR_LAUNCH_CHECK();
     return 0;
   }

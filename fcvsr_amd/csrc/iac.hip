@@ -879,18 +879,32 @@ __global__ __launch_bounds__(256, FCVSR_IAC2_WGS) void iac_fused2_kernel(Iac2Arg
         if (mt & 1) __builtin_amdgcn_sched_barrier(0);   // two M-tiles of operands in flight, not all twelve (96 registers)
       }
     }
+    // LDS float offsets of the lane's records, once per tile for both directions (16 registers; recomputed per phase they were
+    // ~60 VALU instructions per tile of a VALU-bound kernel): ov[cb] = record n, slot (4q + cb) ^ n (vertical reads, v writes: the row is a
+    // scalar offset), oh[tt][cb] = record n + tt - 1, slot (4q + cb) ^ ((n + tt - 1) & 15) (horizontal reads)
+    int ov[4], oh[3][4];
+    {
+      const int x = fresh(), n = x & 15, q = (x & 63) >> 4;
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        ov[cb] = n * kJC + (((q * 4 + cb) ^ n) << 2);
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+          const int m = n + tt - 1;
+          oh[tt][cb] = m * kJC + (((q * 4 + cb) ^ (m & 15)) << 2);
+        }
+      }
+    }
     auto sac = [&](const int dir) {
       float4 vr[4];
       {
-        const int x = fresh(), n = x & 15, q = (x & 63) >> 4;
         // ---- vertical: v[row][n] = sum_t s[row + t][n] * K1[row][n][t] ----
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
           float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int tt = 0; tt < 3; ++tt) {
-            const int P = (wave + tt) * kQVX + n;
-            const float4 sv = *reinterpret_cast<const float4*>(s_s + P * kJC + (((q * 4 + cb) ^ (P & 15)) << 2));
+            const float4 sv = *reinterpret_cast<const float4*>(s_s + (wave + tt) * (kQVX * kJC) + ov[cb]);
             float k[4];
             if (KF) { k[0] = K1f[tt * 4 + cb][0]; k[1] = K1f[tt * 4 + cb][1]; k[2] = K1f[tt * 4 + cb][2]; k[3] = K1f[tt * 4 + cb][3]; }
             else cvt16x4_to_f32<BF>(K1p[tt * 4 + cb], k);
@@ -903,12 +917,8 @@ __global__ __launch_bounds__(256, FCVSR_IAC2_WGS) void iac_fused2_kernel(Iac2Arg
       }
       issue_fin(dir);                                    // the residual is consumed after the next two barriers
       __syncthreads();                                   // every wave has read its three rows of s: v may overwrite rows 0..3
-      {
-        const int x = fresh(), n = x & 15, q = (x & 63) >> 4;
-        const int P = wave * kQVX + n;
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) *reinterpret_cast<float4*>(v_s + P * kJC + (((q * 4 + cb) ^ (P & 15)) << 2)) = vr[cb];
-      }
+      for (int cb = 0; cb < 4; ++cb) *reinterpret_cast<float4*>(v_s + wave * (kQVX * kJC) + ov[cb]) = vr[cb];
       __syncthreads();
       // ---- horizontal (kernel1 again) + residual + LeakyReLU ----
       const int x = fresh(), n = x & 15, q = (x & 63) >> 4;
@@ -926,8 +936,7 @@ __global__ __launch_bounds__(256, FCVSR_IAC2_WGS) void iac_fused2_kernel(Iac2Arg
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int tt = 0; tt < 3; ++tt) {
-              const int P = wave * kQVX + n + tt - 1;
-              const float4 vv = *reinterpret_cast<const float4*>(v_s + P * kJC + (((q * 4 + cb) ^ (P & 15)) << 2));
+              const float4 vv = *reinterpret_cast<const float4*>(v_s + wave * (kQVX * kJC) + oh[tt][cb]);
               float k[4];
               if (KF) { k[0] = K1f[tt * 4 + cb][0]; k[1] = K1f[tt * 4 + cb][1]; k[2] = K1f[tt * 4 + cb][2]; k[3] = K1f[tt * 4 + cb][3]; }
               else cvt16x4_to_f32<BF>(K1p[tt * 4 + cb], k);
@@ -937,7 +946,7 @@ __global__ __launch_bounds__(256, FCVSR_IAC2_WGS) void iac_fused2_kernel(Iac2Arg
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const float r = acc[i] + f[c2 * 4 + i];
-              o[c2 * 4 + i] = r >= 0.f ? r : r * slope;
+              o[c2 * 4 + i] = fmaxf(r, r * slope);       // LeakyReLU for 0 <= slope <= 1 (host-checked): the value of the select form, two ops
             }
           }
           st_p8<ADT>(reinterpret_cast<float*>(db), e + hf * 8, o);
@@ -1131,7 +1140,7 @@ extern "C" int fcvsr_iac_step2_fused(const fcvsr_view* prev, const fcvsr_view* o
     for (const fcvsr_view* v : sets)
       same = same && v[0].sb == v[1].sb && v[0].sy == v[1].sy && v[0].sx == v[1].sx && v[0].sc == v[1].sc && (long long)H * v[0].sy < (1ll << 31);
   }
-  if (form == 2 && same) {   // kernels in registers, three workgroups per CU (iac_fused2_kernel)
+  if (form == 2 && same && slope >= 0.f && slope <= 1.f) {   // kernels in registers, three workgroups per CU (iac_fused2_kernel)
     Iac2Args q;
     for (int d = 0; d < 2; ++d) {
       q.prev[d] = (const uint16_t*)prev[d].ptr; q.off[d] = (const float*)off[d].ptr;
